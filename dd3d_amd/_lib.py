@@ -1,0 +1,113 @@
+"""ctypes binding of libdd3d_hip.so (include/dd3d.h).  The product path has NO fallback: if the library is missing the
+import fails loudly, and calling a kernel without a GPU tensor raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdd3d_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build it with `make -C dd3d_amd/csrc` (or `python -c 'import __graft_entry__ as g; g.build()'`). "
+        "dd3d_amd has no CPU fallback.")
+
+lib = C.CDLL(LIB_PATH)
+
+P, I64, I32, F32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
+
+
+class GSeg(C.Structure):
+    """struct dd3d_gseg (include/dd3d.h)."""
+    _fields_ = [("syn", P), ("real", P), ("dsyn", P), ("rows", I64), ("cols", I64), ("colmajor", I32), ("pad_", I32)]
+
+
+_SIGS = {
+    "dd3d_version": (I32, []),
+    "dd3d_table_capacity": (I64, [I64]),
+    "dd3d_unique_ws_bytes": (I64, [I64, I64]),
+    "dd3d_floor_coords": (I32, [P, I64, P, P]),
+    "dd3d_stride_coords": (I32, [P, P, I64, I32, P, P]),
+    "dd3d_unique_rows": (I32, [P, P, I64, P, I64, P, P, P, P, P, I64, P]),
+    "dd3d_quantize_unique": (I32, [P, I64, P, P, I64, P, P, P, P, P, I64, P]),
+    "dd3d_csr_ws_bytes": (I64, [I64]),
+    "dd3d_voxel_csr": (I32, [P, P, I64, P, P, P, P, I64, P]),
+    "dd3d_kernel_map": (I32, [P, P, I64, P, I64, P, I32, I32, P, I64, P]),
+    "dd3d_pairs_ws_bytes": (I64, [I64, I32]),
+    "dd3d_kernel_map_pairs": (I32, [P, I64, P, I64, I32, P, P, P, P, I64, P]),
+    "dd3d_segment_offsets": (I32, [P, P, I64, I32, P, P, P]),
+    "dd3d_dense_sites": (I32, [P, P, I64, P, I32, I32, I32, I32, I32, I32, P, P, P, P, P]),
+    "dd3d_conv_fwd": (I32, [P, I64, I32, P, I32, P, I64, I32, I64, I32, P, P]),
+    "dd3d_conv_bwd_data": (I32, [P, I64, I32, P, I32, P, I64, I32, P, P]),
+    "dd3d_conv_bwd_weight_ws_bytes": (I64, [I64, I32, I32, I32, I32]),
+    "dd3d_conv_bwd_weight": (I32, [P, I32, P, I32, P, I64, I32, I64, P, I32, P, P, I64, P]),
+    "dd3d_transpose_kernel": (I32, [P, I32, I32, I32, P, P]),
+    "dd3d_voxel_mean_fwd": (I32, [P, I64, I32, P, P, I64, P, P]),
+    "dd3d_voxel_mean_bwd": (I32, [P, I64, I32, P, P, I64, P, P]),
+    "dd3d_inorm_fwd": (I32, [P, P, I32, I32, P, P, P]),
+    "dd3d_inorm_bwd": (I32, [P, P, P, P, I32, I32, P, P]),
+    "dd3d_affine_relu_pool_fwd": (I32, [P, P, P, I32, I32, P, I64, I32, I64, P, P, P]),
+    "dd3d_arp_bwd_ws_bytes": (I64, [I64, I32]),
+    "dd3d_affine_relu_pool_bwd": (I32, [P, P, P, P, P, P, I32, I32, I64, P, I32, P, P, P, P, P, P, P, I64, P]),
+    "dd3d_scale_rows_by_group": (I32, [P, P, P, I32, I64, I32, P, P]),
+    "dd3d_sparse_linear_fwd": (I32, [P, P, P, I32, I32, P, P, P, I32, P, P, P]),
+    "dd3d_sparse_linear_bwd_x": (I32, [P, P, P, I32, I32, P, P, P, I32, I32, P, P]),
+    "dd3d_sparse_linear_bwd_w": (I32, [P, P, P, I32, P, I32, I32, I32, P, P, I64, P]),
+    "dd3d_softmax_ce": (I32, [P, P, P, P, I32, I32, I32, P, P, P, P, P]),
+    "dd3d_softmax_ce_bwd2": (I32, [P, P, P, I32, I32, I32, P, P]),
+    "dd3d_match_loss_ws_bytes": (I64, [P, I32]),
+    "dd3d_match_loss_stats_floats": (I64, [P, I32]),
+    "dd3d_match_loss_fwd": (I32, [P, I32, I32, P, P, P, I64, P]),
+    "dd3d_match_loss_bwd": (I32, [P, I32, I32, P, P, P, I64, P]),
+    "dd3d_sgd_momentum_clamp": (I32, [P, P, P, I64, F32, F32, I32, I32, F32, F32, P]),
+}
+
+EXPORTS = tuple(_SIGS)
+
+for _n, (_r, _a) in _SIGS.items():
+    _f = getattr(lib, _n)  # AttributeError here = header and library disagree
+    _f.restype, _f.argtypes = _r, _a
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Refuses host tensors: there is no CPU path."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("dd3d_amd kernels need GPU tensors (no CPU fallback); got a tensor on " + str(t.device))
+    if not t.is_contiguous():
+        raise RuntimeError("dd3d_amd kernels need contiguous tensors")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(rc: int, name: str):
+    if rc == 0:
+        return
+    if rc < 0:
+        what = {-1: "bad argument", -2: "size out of range", -3: "workspace too small"}.get(rc, "argument error")
+        raise RuntimeError(f"{name}: {what} (rc={rc})")
+    raise RuntimeError(f"{name}: HIP error {rc}")
+
+
+def call(name: str, *args):
+    check(getattr(lib, name)(*args), name)
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes: int, device, tag: str = "ws") -> torch.Tensor:
+    """A per-(device, stream, tag) scratch tensor that only grows (stream-ordered reuse is safe within one stream)."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream, tag)
+    t = _ws_cache.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = t
+    return t

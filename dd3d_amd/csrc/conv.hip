@@ -1,0 +1,422 @@
+// Sparse convolution (MinkowskiConvolution k=3, stride 1; models/MEConv.py:224) for gfx950.
+//
+// Output-stationary gather-GEMM: a workgroup owns a tile of OUTPUT rows and walks the kernel offsets k, gathering the
+// neighbour rows X[nbr[k][o]] into LDS and contracting the channel dimension with W[k] on the fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32: exact fp32, bit-identical to an fmaf chain).  Every output row is written exactly once by
+// exactly one wave, so the "scatter" needs no atomics; offsets (and 64-row wave tiles) without any neighbour are skipped.
+//   forward   : Y[o]  = sum_k X[nbr[k][o]]      . W[k]
+//   bwd-data  : dX[i] = sum_k dY[nbr[K-1-k][i]] . W[k]^T     (stride-1 odd kernels are mirror-symmetric) -> same kernel, mirror=1, W^T
+//   bwd-weight: dW[g][k] = sum_{o in group g} X[nbr[k][o]]^T . dY[o]   -> row-chunk partial slabs + fixed-order reduce (deterministic)
+// Cin == 3 (first layer) is a bandwidth kernel on the VALU (a 3-wide contraction has nothing for MFMA to do).
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// Cin = Cout = 128 forward / backward-data
+// ---------------------------------------------------------------------------------------------
+template <int TM, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void k_conv128(const float* __restrict__ X, const float* __restrict__ W, const int* __restrict__ nbr, int64_t ld,
+                                                 int K, int M_out, int mirror, float* __restrict__ Y) {
+    constexpr int BK = 32, LDA4 = 9 /* (BK+4)/4 float4 per A row: +16 B pad keeps ds_read_b128 conflict-free */;
+    constexpr int WM = TM / WAVES_M, WN = 128 / WAVES_N, MT = WM / 32, NT = WN / 32;
+    static_assert(WAVES_M * WAVES_N == 4 && MT >= 1 && NT >= 1, "4 waves");
+    __shared__ f32x4 As4[TM * LDA4];
+    __shared__ f32x4 Bs4[BK * 32];
+    __shared__ int s_nbr[27 * TM];
+    __shared__ unsigned s_kmask;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int i32 = lane & 31, h = lane >> 5;
+    const int wrow0 = (wid / WAVES_N) * WM, wcol0 = (wid % WAVES_N) * WN;
+    const int64_t row0 = (int64_t)blockIdx.x * TM;
+
+    if (tid == 0) s_kmask = 0;
+    __syncthreads();
+    unsigned mymask = 0;
+    for (int idx = tid; idx < K * TM; idx += 256) {
+        int k = idx / TM, r = idx - k * TM;
+        int64_t row = row0 + r;
+        int ks = mirror ? K - 1 - k : k;
+        int v = row < M_out ? nbr[(int64_t)ks * ld + row] : -1;
+        s_nbr[idx] = v;
+        if (v >= 0) mymask |= 1u << k;
+    }
+    if (mymask) atomicOr(&s_kmask, mymask);
+    __syncthreads();
+    const unsigned kmask = s_kmask;
+    // which offsets have a neighbour for THIS wave's rows
+    unsigned wmask = 0;
+    for (int k = 0; k < K; ++k) {
+        if (!((kmask >> k) & 1u)) continue;
+        bool v = false;
+        for (int r = lane; r < WM; r += 64) v |= s_nbr[k * TM + wrow0 + r] >= 0;
+        if (__ballot(v)) wmask |= 1u << k;
+    }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const f32x4* X4 = (const f32x4*)X;
+    const f32x4* W4 = (const f32x4*)W;
+    const float* Bs = (const float*)Bs4;
+
+    for (int k = 0; k < K; ++k) {
+        if (!((kmask >> k) & 1u)) continue;
+        const bool wave_on = (wmask >> k) & 1u;
+        for (int kc = 0; kc < 4; ++kc) {
+            // ---- stage the gathered A tile [TM][32] and the W[k] slice [32][128] ----
+#pragma unroll
+            for (int j = 0; j < TM / 32; ++j) {
+                int idx = j * 256 + tid;
+                int r = idx >> 3, q = idx & 7;
+                int nb = s_nbr[k * TM + r];
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (nb >= 0) v = X4[(int64_t)nb * 32 + kc * 8 + q];
+                As4[r * LDA4 + q] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int idx = j * 256 + tid;
+                int kr = idx >> 5, q = idx & 31;
+                Bs4[idx] = W4[((int64_t)k * 128 + kc * 32 + kr) * 32 + q];
+            }
+            __syncthreads();
+            if (wave_on) {
+                f32x4 a[MT][4];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[m][j] = As4[(wrow0 + m * 32 + i32) * LDA4 + h * 4 + j];
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    float b[NT];
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) b[n] = Bs[(h * 16 + s) * 128 + wcol0 + n * 32 + i32];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][s >> 2][s & 3], b[n], acc[m][n], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int64_t row = row0 + wrow0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < M_out) Y[row * 128 + wcol0 + n * 32 + i32] = acc[m][n][r];
+            }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cin = Cout = 128 backward-weight: one workgroup per (row chunk, offset k) -> partial slab [128][128]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_conv128_bww(const float* __restrict__ X, const float* __restrict__ dY, const int* __restrict__ nbr, int64_t ld,
+                                                     int K, const int* __restrict__ group_row_off, int G, int CH, float* __restrict__ slabs,
+                                                     int* __restrict__ slab_valid) {
+    __shared__ f32x4 As4[32 * 32];
+    __shared__ f32x4 Ds4[32 * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int i32 = lane & 31, h = lane >> 5;
+    const int wm0 = (wid >> 1) * 64, wn0 = (wid & 1) * 64;
+    const int c = blockIdx.x, k = blockIdx.y;
+    int g, r0, r1;
+    if (!resolve_chunk(c, group_row_off, G, CH, &g, &r0, &r1)) return;
+    const int* nk = nbr + (int64_t)k * ld;
+    int any = 0;
+    for (int r = r0 + tid; r < r1; r += 256) any |= nk[r] >= 0;
+    if (!__syncthreads_or(any)) return;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    const f32x4* X4 = (const f32x4*)X;
+    const f32x4* D4 = (const f32x4*)dY;
+    const float* As = (const float*)As4;
+    const float* Ds = (const float*)Ds4;
+
+    for (int rb = r0; rb < r1; rb += 32) {
+        int have = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int idx = j * 256 + tid;
+            int r = idx >> 5, q = idx & 31;
+            int row = rb + r;
+            int nb = row < r1 ? nk[row] : -1;
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
+            if (nb >= 0) {
+                a = X4[(int64_t)nb * 32 + q];
+                d = D4[(int64_t)row * 32 + q];
+                have = 1;
+            }
+            As4[idx] = a;
+            Ds4[idx] = d;
+        }
+        if (__syncthreads_or(have)) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                float a[2], b[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) a[m] = As[(h * 16 + s) * 128 + wm0 + m * 32 + i32];
+#pragma unroll
+                for (int n = 0; n < 2; ++n) b[n] = Ds[(h * 16 + s) * 128 + wn0 + n * 32 + i32];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    float* slab = slabs + ((int64_t)c * K + k) * (128 * 128);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int ci = wm0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                slab[ci * 128 + wn0 + n * 32 + i32] = acc[m][n][r];
+            }
+    if (tid == 0) slab_valid[(int64_t)c * K + k] = 1;
+}
+
+// dW[g][k][e] = sum over the valid slabs of group g, in slot order (deterministic)
+__global__ void k_slab_reduce(const f32x4* __restrict__ slabs, const int* __restrict__ slab_valid, const int* __restrict__ group_row_off, int G, int CH,
+                              int K, int elems4, f32x4* __restrict__ dW) {
+    int e = blockIdx.x * 256 + threadIdx.x;
+    int k = blockIdx.y, g = blockIdx.z;
+    if (e >= elems4) return;
+    int first = 0;
+    for (int j = 0; j < g; ++j) first += (group_row_off[j + 1] - group_row_off[j] + CH - 1) / CH;
+    int n = (group_row_off[g + 1] - group_row_off[g] + CH - 1) / CH;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int c = first; c < first + n; ++c)
+        if (slab_valid[(int64_t)c * K + k]) s += slabs[((int64_t)c * K + k) * elems4 + e];
+    dW[((int64_t)g * K + k) * elems4 + e] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cin = 3, Cout = 128 (first layer): bandwidth kernels on the VALU
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_conv3_fwd(const float* __restrict__ X, const float* __restrict__ W /*[K][3][128]*/, const int* __restrict__ nbr,
+                                                   int64_t ld, int K, int M_out, int rows_per_block, float* __restrict__ Y) {
+    __shared__ f32x4 Ws4[27 * 3 * 32];
+    const int tid = threadIdx.x;
+    const f32x4* W4 = (const f32x4*)W;
+    for (int i = tid; i < K * 3 * 32; i += 256) Ws4[i] = W4[i];
+    __syncthreads();
+    const int c4 = tid & 31, rl = tid >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * rows_per_block;
+    f32x4* Y4 = (f32x4*)Y;
+    for (int it = 0; it < rows_per_block; it += 8) {
+        int64_t row = row0 + it + rl;
+        bool live = row < M_out;
+        int mynb = (live && c4 < K) ? nbr[(int64_t)c4 * ld + row] : -1;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < K; ++k) {
+            int nb = __shfl(mynb, k, 32);
+            if (nb >= 0) {
+                const float* x = X + (int64_t)nb * 3;
+                float x0 = x[0], x1 = x[1], x2 = x[2];
+                acc += x0 * Ws4[(k * 3 + 0) * 32 + c4];
+                acc += x1 * Ws4[(k * 3 + 1) * 32 + c4];
+                acc += x2 * Ws4[(k * 3 + 2) * 32 + c4];
+            }
+        }
+        if (live) Y4[row * 32 + c4] = acc;
+    }
+}
+
+// dX[i][ci] = sum_k sum_co dY[nbr[K-1-k][i]][co] * W[k][ci][co]
+__global__ __launch_bounds__(256) void k_conv3_bwd_data(const float* __restrict__ dY, const float* __restrict__ W, const int* __restrict__ nbr, int64_t ld,
+                                                        int K, int M, int rows_per_block, float* __restrict__ dX) {
+    __shared__ f32x4 Ws4[27 * 3 * 32];
+    const int tid = threadIdx.x;
+    const f32x4* W4 = (const f32x4*)W;
+    for (int i = tid; i < K * 3 * 32; i += 256) Ws4[i] = W4[i];
+    __syncthreads();
+    const int c4 = tid & 31, rl = tid >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * rows_per_block;
+    const f32x4* D4 = (const f32x4*)dY;
+    for (int it = 0; it < rows_per_block; it += 8) {
+        int64_t row = row0 + it + rl;
+        bool live = row < M;
+        int mynb = (live && c4 < K) ? nbr[(int64_t)(K - 1 - c4) * ld + row] : -1;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        for (int k = 0; k < K; ++k) {
+            int nb = __shfl(mynb, k, 32);
+            if (nb >= 0) {
+                f32x4 d = D4[(int64_t)nb * 32 + c4];
+                f32x4 w0 = Ws4[(k * 3 + 0) * 32 + c4], w1 = Ws4[(k * 3 + 1) * 32 + c4], w2 = Ws4[(k * 3 + 2) * 32 + c4];
+                s0 += d[0] * w0[0] + d[1] * w0[1] + d[2] * w0[2] + d[3] * w0[3];
+                s1 += d[0] * w1[0] + d[1] * w1[1] + d[2] * w1[2] + d[3] * w1[3];
+                s2 += d[0] * w2[0] + d[1] * w2[1] + d[2] * w2[2] + d[3] * w2[3];
+            }
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            s0 += __shfl_xor(s0, o, 32);
+            s1 += __shfl_xor(s1, o, 32);
+            s2 += __shfl_xor(s2, o, 32);
+        }
+        if (live && c4 == 0) {
+            dX[row * 3 + 0] = s0;
+            dX[row * 3 + 1] = s1;
+            dX[row * 3 + 2] = s2;
+        }
+    }
+}
+
+// dW[g][k][ci][co] partial per row chunk: thread = output channel, 81 accumulators in registers (fully unrolled over k)
+__global__ __launch_bounds__(128) void k_conv3_bww(const float* __restrict__ X, const float* __restrict__ dY, const int* __restrict__ nbr, int64_t ld,
+                                                   const int* __restrict__ group_row_off, int G, int CH, float* __restrict__ slabs, int* __restrict__ slab_valid) {
+    const int co = threadIdx.x;
+    const int c = blockIdx.x;
+    int g, r0, r1;
+    if (!resolve_chunk(c, group_row_off, G, CH, &g, &r0, &r1)) return;
+    float acc[81];
+#pragma unroll
+    for (int i = 0; i < 81; ++i) acc[i] = 0.f;
+    for (int r = r0; r < r1; ++r) {
+        float dy = dY[(int64_t)r * 128 + co];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) {
+            int nb = nbr[(int64_t)k * ld + r];  // wave-uniform
+            if (nb >= 0) {
+                const float* x = X + (int64_t)nb * 3;
+                acc[k * 3 + 0] += x[0] * dy;
+                acc[k * 3 + 1] += x[1] * dy;
+                acc[k * 3 + 2] += x[2] * dy;
+            }
+        }
+    }
+    float* slab = slabs + (int64_t)c * (81 * 128);
+#pragma unroll
+    for (int i = 0; i < 81; ++i) slab[i * 128 + co] = acc[i];
+    if (co == 0) slab_valid[c] = 1;
+}
+
+__global__ void k_transpose_kernel(const float* __restrict__ W, int K, int Cin, int Cout, float* __restrict__ Wt) {
+    // Wt[k][co][ci] = W[k][ci][co]
+    __shared__ float tile[32][33];
+    int k = blockIdx.z;
+    int ci0 = blockIdx.y * 32, co0 = blockIdx.x * 32;
+    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        int ci = ci0 + j, co = co0 + tx;
+        tile[j][tx] = (ci < Cin && co < Cout) ? W[((int64_t)k * Cin + ci) * Cout + co] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        int co = co0 + j, ci = ci0 + tx;
+        if (ci < Cin && co < Cout) Wt[((int64_t)k * Cout + co) * Cin + ci] = tile[tx][j];
+    }
+}
+
+int pick_chunk(int64_t M) {
+    // about 256 row chunks per launch, at least 512 rows each, a multiple of 32
+    int64_t ch = align_up64(ceil_div64(M > 0 ? M : 1, 256), 32);
+    if (ch < 512) ch = 512;
+    return (int)ch;
+}
+
+}  // namespace
+
+DD3D_API int dd3d_conv_chunk_rows(int64_t M) { return pick_chunk(M); }
+
+DD3D_API int64_t dd3d_conv_bwd_weight_ws_bytes(int64_t M_out, int G, int K, int Cin, int Cout) {
+    int CH = pick_chunk(M_out);
+    int64_t slots = ceil_div64(M_out, CH) + G;
+    int64_t nslab = (Cin == 3) ? slots : slots * K;
+    int64_t per = (Cin == 3) ? (int64_t)K * 3 * Cout : (int64_t)Cin * Cout;
+    return align_up64(nslab * per * 4, 256) + align_up64(nslab * 4, 256);
+}
+
+// Y[M_out,Cout] = sum_k X[nbr[k'][o]] . Wmat[k],  k' = mirror ? K-1-k : k.   Wmat is [K,Cin,Cout] row-major.
+DD3D_API int dd3d_conv_fwd(const float* X, int64_t M_in, int Cin, const float* W, int Cout, const int32_t* nbr, int64_t ld, int K, int64_t M_out,
+                           int mirror, float* Y, void* stream) {
+    if (M_out < 0 || M_in < 0 || K != 27 || ld < M_out || Cout != 128 || (Cin != 3 && Cin != 128)) return DD3D_EARG;
+    if (M_out >= (1ll << 31) / 128 * 16) return DD3D_ESIZE;
+    if (M_out == 0) return 0;
+    if (!X || !W || !nbr || !Y) return DD3D_EARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (Cin == 3) {
+        if (mirror) return DD3D_EARG;
+        const int rpb = 64;
+        k_conv3_fwd<<<dim3((unsigned)ceil_div64(M_out, rpb)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, rpb, Y);
+    } else if (M_out >= 128 * 512) {
+        k_conv128<128, 2, 2><<<dim3((unsigned)ceil_div64(M_out, 128)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, mirror, Y);
+    } else {
+        k_conv128<64, 1, 4><<<dim3((unsigned)ceil_div64(M_out, 64)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, mirror, Y);
+    }
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}
+
+// dX[M,Cin] for a stride-1 convolution.  Cin==128: pass Wt = transposed kernel [K,Cout,Cin] (dd3d_transpose_kernel); Cin==3: pass W itself.
+DD3D_API int dd3d_conv_bwd_data(const float* dY, int64_t M, int Cout, const float* W_or_Wt, int Cin, const int32_t* nbr, int64_t ld, int K, float* dX,
+                                void* stream) {
+    if (Cin == 128) return dd3d_conv_fwd(dY, M, Cout, W_or_Wt, Cin, nbr, ld, K, M, 1, dX, stream);
+    if (M < 0 || K != 27 || ld < M || Cout != 128 || Cin != 3) return DD3D_EARG;
+    if (M == 0) return 0;
+    if (!dY || !W_or_Wt || !nbr || !dX) return DD3D_EARG;
+    const int rpb = 64;
+    k_conv3_bwd_data<<<dim3((unsigned)ceil_div64(M, rpb)), 256, 0, (hipStream_t)stream>>>(dY, W_or_Wt, nbr, ld, K, (int)M, rpb, dX);
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}
+
+// dW[G,K,Cin,Cout]; rows of group g are [group_row_off[g], group_row_off[g+1]) (device array, G+1 ints)
+DD3D_API int dd3d_conv_bwd_weight(const float* X, int Cin, const float* dY, int Cout, const int32_t* nbr, int64_t ld, int K, int64_t M_out,
+                                  const int32_t* group_row_off, int G, float* dW, void* ws, int64_t ws_bytes, void* stream) {
+    if (M_out < 0 || K != 27 || ld < M_out || Cout != 128 || (Cin != 3 && Cin != 128) || G <= 0 || !group_row_off || !dW) return DD3D_EARG;
+    if (ws_bytes < dd3d_conv_bwd_weight_ws_bytes(M_out, G, K, Cin, Cout) || !ws) return DD3D_EWS;
+    hipStream_t st = (hipStream_t)stream;
+    int CH = pick_chunk(M_out);
+    int64_t slots = ceil_div64(M_out, CH) + G;
+    int64_t nslab = (Cin == 3) ? slots : slots * K;
+    int64_t per = (Cin == 3) ? (int64_t)K * 3 * Cout : (int64_t)Cin * Cout;
+    float* slabs = (float*)ws;
+    int* valid = (int*)((char*)ws + align_up64(nslab * per * 4, 256));
+    DD3D_HIP(hipMemsetAsync(valid, 0, nslab * 4, st));
+    if (M_out > 0) {
+        if (!X || !dY || !nbr) return DD3D_EARG;
+        if (Cin == 3)
+            k_conv3_bww<<<dim3((unsigned)slots), 128, 0, st>>>(X, dY, nbr, ld, group_row_off, G, CH, slabs, valid);
+        else
+            k_conv128_bww<<<dim3((unsigned)slots, K), 256, 0, st>>>(X, dY, nbr, ld, K, group_row_off, G, CH, slabs, valid);
+    }
+    if (Cin == 3)
+        k_slab_reduce<<<dim3((unsigned)ceil_div64(per / 4, 256), 1, G), 256, 0, st>>>((const f32x4*)slabs, valid, group_row_off, G, CH, 1, (int)(per / 4),
+                                                                                     (f32x4*)dW);
+    else
+        k_slab_reduce<<<dim3((unsigned)ceil_div64(per / 4, 256), K, G), 256, 0, st>>>((const f32x4*)slabs, valid, group_row_off, G, CH, K, (int)(per / 4),
+                                                                                     (f32x4*)dW);
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}
+
+DD3D_API int dd3d_transpose_kernel(const float* W, int K, int Cin, int Cout, float* Wt, void* stream) {
+    if (K <= 0 || Cin <= 0 || Cout <= 0 || !W || !Wt) return DD3D_EARG;
+    dim3 grid((Cout + 31) / 32, (Cin + 31) / 32, K);
+    k_transpose_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(W, K, Cin, Cout, Wt);
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}

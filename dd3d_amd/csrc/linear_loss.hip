@@ -1,0 +1,467 @@
+// (a) Sparse-aware classifier: SparseTensor.dense() + nn.Linear(100352,10) (models/MEConv.py:250-256) without ever
+//     materialising the [B,100352] dense tensor.  A voxel v of cloud b with dense site s = site[v] touches the C weight columns
+//     {c*S + s}; all three products below are closed under differentiation, which is what the second-order part of the
+//     matching loss needs (the reference gets it from torch autograd through index_put / addmm):
+//        fwd   : out[b][j]          = sum_{v in b} sum_c F[v][c] * Wl[g(b)][j][c][s]
+//        bwd_x : dF[v][c]           = sum_j dl[b(v)][j] * Wl[g][j][c][s]
+//        bwd_w : dWl[g][j][c][s]    = sum_{b in g, v = vox_at[b][s]} dl[b][j] * F[v][c]
+//     Wl is addressed with explicit element strides so that both the parameter layout [J, C*S] and a site-major copy work.
+// (b) The gradient distance of distillation_loss.py:26-130 as one segmented reduction over all layers + its backward.
+// (c) softmax cross-entropy (mean over a group's clouds) with first and second-order backward, and the SGD/clamp update of
+//     mnist_distill.py:311-317,369 for the batched step.
+#include "common.h"
+#include "../../include/dd3d.h"
+
+namespace {
+
+struct WStride {
+    int64_t g, j, c, s;
+};
+
+__global__ __launch_bounds__(256) void k_sl_fwd(const float* __restrict__ F, const int* __restrict__ site, const int* __restrict__ seg_off,
+                                                const int* __restrict__ cloud_group, const float* __restrict__ Wl, WStride ws, int J,
+                                                const float* __restrict__ bias, float* __restrict__ out) {
+    __shared__ float s_part[64 * 4];
+    const int b = blockIdx.x, tid = threadIdx.x, c = tid & 127, rl = tid >> 7, lane = tid & 63, wid = tid >> 6;
+    const int r0 = seg_off[b], r1 = seg_off[b + 1];
+    const int g = cloud_group ? cloud_group[b] : 0;
+    const float* Wg = Wl + g * ws.g + c * ws.c;
+    for (int j0 = 0; j0 < J; j0 += 64) {
+        int jn = min(64, J - j0);
+        for (int jj = 0; jj < jn; ++jj) {
+            const float* Wj = Wg + (int64_t)(j0 + jj) * ws.j;
+            float acc = 0.f;
+            for (int v = r0 + rl; v < r1; v += 2) {
+                int s = site[v];
+                if (s >= 0) acc += F[(int64_t)v * 128 + c] * Wj[s * ws.s];
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) s_part[jj * 4 + wid] = acc;
+        }
+        __syncthreads();
+        if (tid < jn) {
+            float s = s_part[tid * 4] + s_part[tid * 4 + 1] + s_part[tid * 4 + 2] + s_part[tid * 4 + 3];
+            if (bias) s += bias[j0 + tid];
+            out[(int64_t)b * J + j0 + tid] = s;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sl_bwd_x(const float* __restrict__ dl, const int* __restrict__ site, const int* __restrict__ seg_off,
+                                                  const int* __restrict__ cloud_group, const float* __restrict__ Wl, WStride ws, int J,
+                                                  int accumulate, float* __restrict__ dF) {
+    extern __shared__ float s_dl[];
+    const int b = blockIdx.x, tid = threadIdx.x, c = tid & 127, rl = tid >> 7;
+    const int r0 = seg_off[b], r1 = seg_off[b + 1];
+    const int g = cloud_group ? cloud_group[b] : 0;
+    for (int j = tid; j < J; j += 256) s_dl[j] = dl[(int64_t)b * J + j];
+    __syncthreads();
+    const float* Wg = Wl + g * ws.g + c * ws.c;
+    for (int v = r0 + rl; v < r1; v += 2) {
+        int s = site[v];
+        float acc = 0.f;
+        if (s >= 0)
+            for (int j = 0; j < J; ++j) acc += s_dl[j] * Wg[(int64_t)j * ws.j + s * ws.s];
+        int64_t o = (int64_t)v * 128 + c;
+        dF[o] = accumulate ? dF[o] + acc : acc;
+    }
+}
+
+// grid (S, G); 128 threads = channels; writes only the sites some cloud of the group occupies (the caller zero-fills the rest)
+__global__ __launch_bounds__(128) void k_sl_bwd_w(const float* __restrict__ dl, const float* __restrict__ F, const int* __restrict__ vox_at, int S,
+                                                  const int* __restrict__ group_cloud_off, int J, float* __restrict__ dWl, WStride ws) {
+    const int s = blockIdx.x, g = blockIdx.y, c = threadIdx.x;
+    const int b0 = group_cloud_off[g], b1 = group_cloud_off[g + 1];
+    int any = 0;
+    for (int b = b0 + c; b < b1; b += 128) any |= vox_at[(int64_t)b * S + s] >= 0;
+    if (!__syncthreads_or(any)) return;
+    float* out = dWl + g * ws.g + c * ws.c + s * ws.s;
+    for (int j0 = 0; j0 < J; j0 += 8) {
+        float acc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+        for (int b = b0; b < b1; ++b) {
+            int v = vox_at[(int64_t)b * S + s];  // wave-uniform
+            if (v < 0) continue;
+            float f = F[(int64_t)v * 128 + c];
+            const float* d = dl + (int64_t)b * J + j0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (j0 + u < J) acc[u] += d[u] * f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (j0 + u < J) out[(int64_t)(j0 + u) * ws.j] = acc[u];
+    }
+}
+
+// ---- softmax cross-entropy over [B,J] logits, mean over the clouds of each group --------------------------------
+// per cloud: p = softmax(z), dlogits = (p - onehot)/B_g, cloud_loss = (lse - z[y])/B_g ; then one thread per group sums in order
+__global__ void k_softmax_ce(const float* __restrict__ logits, const int* __restrict__ labels, const int* __restrict__ cloud_group,
+                             const int* __restrict__ group_cloud_off, int B, int J, float* __restrict__ prob, float* __restrict__ dlogits,
+                             float* __restrict__ cloud_loss) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int g = cloud_group ? cloud_group[b] : 0;
+    float inv = 1.0f / (float)max(group_cloud_off[g + 1] - group_cloud_off[g], 1);
+    const float* z = logits + (int64_t)b * J;
+    float m = z[0];
+    for (int j = 1; j < J; ++j) m = fmaxf(m, z[j]);
+    float se = 0.f;
+    for (int j = 0; j < J; ++j) se += expf(z[j] - m);
+    float lse = m + logf(se);
+    int y = labels[b];
+    for (int j = 0; j < J; ++j) {
+        float p = expf(z[j] - lse);
+        if (prob) prob[(int64_t)b * J + j] = p;
+        dlogits[(int64_t)b * J + j] = (p - (j == y ? 1.f : 0.f)) * inv;
+    }
+    cloud_loss[b] = (lse - z[y]) * inv;
+}
+
+__global__ void k_group_sum(const float* __restrict__ v, const int* __restrict__ group_cloud_off, int G, float* __restrict__ out) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    float s = 0.f;
+    for (int b = group_cloud_off[g]; b < group_cloud_off[g + 1]; ++b) s += v[b];
+    out[g] = s;
+}
+
+// second order: dlogits = (softmax(z) - onehot)/B_g ; given u = dL/d(dlogits) -> dz = p * (u - <p,u>) / B_g
+__global__ void k_softmax_ce_bwd2(const float* __restrict__ prob, const float* __restrict__ u, const int* __restrict__ group_cloud_off, int G, int J,
+                                  float* __restrict__ dz) {
+    int g = blockIdx.y;
+    int b = group_cloud_off[g] + blockIdx.x * blockDim.x + threadIdx.x;
+    int b1 = group_cloud_off[g + 1];
+    if (b >= b1) return;
+    float inv = 1.0f / (float)(b1 - group_cloud_off[g]);
+    const float* p = prob + (int64_t)b * J;
+    const float* uu = u + (int64_t)b * J;
+    float d = 0.f;
+    for (int j = 0; j < J; ++j) d += p[j] * uu[j];
+    for (int j = 0; j < J; ++j) dz[(int64_t)b * J + j] = p[j] * (uu[j] - d) * inv;
+}
+
+// ---- gradient distance ------------------------------------------------------------------------------------------
+constexpr int GD_ROW_CHUNK = 8192;  // elements of one contiguous row per work item
+constexpr int GD_COL_CHUNK = 64;    // logical columns per work item in column-major segments (128 rows per item)
+
+struct GPlan {
+    int n, metric;
+    int item_off[DD3D_MAX_SEG + 1];  // work items per segment (prefix)
+    int row_off[DD3D_MAX_SEG + 1];   // logical rows per segment (prefix)
+    int part_off[DD3D_MAX_SEG + 1];  // partial records (row x chunk) per segment (prefix)
+    int nchunk[DD3D_MAX_SEG];
+    dd3d_gseg seg[DD3D_MAX_SEG];
+};
+
+__device__ __forceinline__ int find_seg(const GPlan& p, int item) {
+    int s = 0;
+    while (s + 1 < p.n && item >= p.item_off[s + 1]) ++s;
+    return s;
+}
+
+// partial[(part_off[s] + row*nchunk + chunk)] = (dot, ss, rr, sqdiff) over the item's elements
+__global__ __launch_bounds__(256) void k_gd_stats(const GPlan p, float4* __restrict__ partial) {
+    __shared__ float s_red[4 * 4];
+    __shared__ float4 s_half[128];
+    const int item = blockIdx.x, tid = threadIdx.x;
+    const int s = find_seg(p, item);
+    const dd3d_gseg sg = p.seg[s];
+    const int local = item - p.item_off[s];
+    const int nch = p.nchunk[s];
+    if (!sg.colmajor) {
+        int row = local / nch, ch = local - row * nch;
+        int64_t e0 = (int64_t)ch * GD_ROW_CHUNK, e1 = min(e0 + GD_ROW_CHUNK, sg.cols);
+        const float* a = sg.syn + row * sg.cols;
+        const float* b = sg.real + row * sg.cols;
+        float dot = 0.f, ss = 0.f, rr = 0.f, sq = 0.f;
+        for (int64_t e = e0 + tid; e < e1; e += 256) {
+            float x = a[e], y = b[e], d = x - y;
+            dot += x * y; ss += x * x; rr += y * y; sq += d * d;
+        }
+        dot = wave_sum(dot); ss = wave_sum(ss); rr = wave_sum(rr); sq = wave_sum(sq);
+        if ((tid & 63) == 0) {
+            int w = tid >> 6;
+            s_red[w * 4 + 0] = dot; s_red[w * 4 + 1] = ss; s_red[w * 4 + 2] = rr; s_red[w * 4 + 3] = sq;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float4 o;
+            o.x = s_red[0] + s_red[4] + s_red[8] + s_red[12];
+            o.y = s_red[1] + s_red[5] + s_red[9] + s_red[13];
+            o.z = s_red[2] + s_red[6] + s_red[10] + s_red[14];
+            o.w = s_red[3] + s_red[7] + s_red[11] + s_red[15];
+            partial[p.part_off[s] + (int64_t)row * nch + ch] = o;
+        }
+    } else {
+        // logical row r = memory-contiguous index; logical column q strides by `rows`
+        int rtile = local / nch, ch = local - rtile * nch;
+        int r = rtile * 128 + (tid & 127), half = tid >> 7;
+        int64_t q0 = (int64_t)ch * GD_COL_CHUNK, q1 = min(q0 + GD_COL_CHUNK, sg.cols);
+        float dot = 0.f, ss = 0.f, rr = 0.f, sq = 0.f;
+        if (r < sg.rows)
+            for (int64_t q = q0 + half; q < q1; q += 2) {
+                float x = sg.syn[q * sg.rows + r], y = sg.real[q * sg.rows + r], d = x - y;
+                dot += x * y; ss += x * x; rr += y * y; sq += d * d;
+            }
+        if (half == 1) s_half[tid & 127] = make_float4(dot, ss, rr, sq);
+        __syncthreads();
+        if (half == 0 && r < sg.rows) {
+            float4 t = s_half[tid];
+            partial[p.part_off[s] + (int64_t)r * nch + ch] = make_float4(dot + t.x, ss + t.y, rr + t.z, sq + t.w);
+        }
+    }
+}
+
+__device__ __forceinline__ float row_term(int metric, float4 st) {
+    if (metric == 0) return 1.0f - st.x / (sqrtf(st.z) * sqrtf(st.y) + 0.000001f);
+    return st.w;
+}
+
+// one block: per-row stats in chunk order, then the loss in (segment,row) order -> fully deterministic
+__global__ __launch_bounds__(256) void k_gd_finalize(const GPlan p, const float4* __restrict__ partial, float4* __restrict__ stats,
+                                                     float* __restrict__ loss) {
+    __shared__ float s_term[256];
+    __shared__ float4 s_tot[256];
+    const int tid = threadIdx.x;
+    const int total_rows = p.row_off[p.n];
+    float run = 0.f;
+    float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = 0; base < total_rows; base += 256) {
+        int gr = base + tid;
+        float term = 0.f;
+        float4 st = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gr < total_rows) {
+            int s = 0;
+            while (s + 1 < p.n && gr >= p.row_off[s + 1]) ++s;
+            int row = gr - p.row_off[s];
+            int nch = p.nchunk[s];
+            const float4* pp = partial + p.part_off[s] + (int64_t)row * nch;
+            for (int c = 0; c < nch; ++c) {
+                float4 v = pp[c];
+                st.x += v.x; st.y += v.y; st.z += v.z; st.w += v.w;
+            }
+            stats[gr] = st;
+            term = row_term(p.metric, st);
+        }
+        s_term[tid] = term;
+        s_tot[tid] = st;
+        __syncthreads();
+        if (tid == 0) {
+            int n = min(256, total_rows - base);
+            for (int i = 0; i < n; ++i) {
+                run += s_term[i];
+                tot.x += s_tot[i].x; tot.y += s_tot[i].y; tot.z += s_tot[i].z; tot.w += s_tot[i].w;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        float L;
+        if (p.metric == 0 || p.metric == 1) L = run;
+        else if (p.metric == 2) L = tot.w;
+        else L = 1.0f - tot.x / (sqrtf(tot.z) * sqrtf(tot.y) + 0.000001f);
+        loss[0] = L;
+        stats[total_rows] = tot;  // global record used by the 'cos' backward
+    }
+}
+
+// d loss / d syn for every segment with a dsyn buffer
+__global__ __launch_bounds__(256) void k_gd_bwd(const GPlan p, const float4* __restrict__ stats, const float* __restrict__ gl) {
+    const int item = blockIdx.x, tid = threadIdx.x;
+    const int s = find_seg(p, item);
+    const dd3d_gseg sg = p.seg[s];
+    if (!sg.dsyn) return;
+    const int local = item - p.item_off[s];
+    const int nch = p.nchunk[s];
+    const float up = gl ? gl[0] : 1.0f;
+    const int total_rows = p.row_off[p.n];
+    const int metric = p.metric;
+    auto coef = [&](float4 st, float* ca, float* cb) {
+        // d/ds [1 - <r,s>/(|r||s|+eps)] = -r/den + <r,s>*|r|/(|s|*den^2) * s
+        float nr = sqrtf(st.z), ns = sqrtf(st.y), den = nr * ns + 0.000001f;
+        *ca = -up / den;
+        *cb = ns > 0.f ? up * st.x * nr / (ns * den * den) : 0.f;
+    };
+    if (!sg.colmajor) {
+        int row = local / nch, ch = local - row * nch;
+        int64_t e0 = (int64_t)ch * GD_ROW_CHUNK, e1 = min(e0 + GD_ROW_CHUNK, sg.cols);
+        const float* a = sg.syn + row * sg.cols;
+        const float* b = sg.real + row * sg.cols;
+        float* d = sg.dsyn + row * sg.cols;
+        float ca = 0.f, cb = 0.f;
+        if (metric == 0) coef(stats[p.row_off[s] + row], &ca, &cb);
+        else if (metric == 3) coef(stats[total_rows], &ca, &cb);
+        for (int64_t e = e0 + tid; e < e1; e += 256) {
+            float x = a[e], y = b[e];
+            d[e] = (metric == 1 || metric == 2) ? 2.0f * up * (x - y) : ca * y + cb * x;
+        }
+    } else {
+        int rtile = local / nch, ch = local - rtile * nch;
+        int r = rtile * 128 + (tid & 127), half = tid >> 7;
+        if (r >= sg.rows) return;
+        int64_t q0 = (int64_t)ch * GD_COL_CHUNK, q1 = min(q0 + GD_COL_CHUNK, sg.cols);
+        float ca = 0.f, cb = 0.f;
+        if (metric == 0) coef(stats[p.row_off[s] + r], &ca, &cb);
+        else if (metric == 3) coef(stats[total_rows], &ca, &cb);
+        for (int64_t q = q0 + half; q < q1; q += 2) {
+            int64_t e = q * sg.rows + r;
+            float x = sg.syn[e], y = sg.real[e];
+            sg.dsyn[e] = (metric == 1 || metric == 2) ? 2.0f * up * (x - y) : ca * y + cb * x;
+        }
+    }
+}
+
+// SGD with momentum on the synthetic xyz + the clamp of the NEXT iteration's prologue (mnist_distill.py:311-317,369)
+__global__ void k_sgd_clamp(float* __restrict__ x, const float* __restrict__ grad, float* __restrict__ mom, int64_t n, float lr, float momentum,
+                            int first_step, int do_clamp, float lo, float hi) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float g = grad[i];
+    float m = first_step ? g : momentum * mom[i] + g;
+    mom[i] = m;
+    float v = x[i] - lr * m;
+    if (do_clamp) {
+        v = v < lo ? lo : v;
+        v = v > hi ? hi : v;
+        if (i % 3 == 0) v = 0.f;
+    }
+    x[i] = v;
+}
+
+int build_plan(const dd3d_gseg* segs, int n, int metric, GPlan* p) {
+    if (n <= 0 || n > DD3D_MAX_SEG || metric < 0 || metric > 3 || !segs) return DD3D_EARG;
+    p->n = n;
+    p->metric = metric;
+    p->item_off[0] = p->row_off[0] = p->part_off[0] = 0;
+    for (int s = 0; s < n; ++s) {
+        const dd3d_gseg& g = segs[s];
+        if (g.rows <= 0 || g.cols <= 0 || !g.syn || !g.real) return DD3D_EARG;
+        int64_t nch, items;
+        if (!g.colmajor) {
+            nch = ceil_div64(g.cols, GD_ROW_CHUNK);
+            items = g.rows * nch;
+        } else {
+            nch = ceil_div64(g.cols, GD_COL_CHUNK);
+            items = ceil_div64(g.rows, 128) * nch;
+        }
+        if (items > (1 << 24) || g.rows > (1 << 22)) return DD3D_ESIZE;
+        p->nchunk[s] = (int)nch;
+        p->item_off[s + 1] = p->item_off[s] + (int)items;
+        p->row_off[s + 1] = p->row_off[s] + (int)g.rows;
+        p->part_off[s + 1] = p->part_off[s] + (int)(g.rows * nch);
+        p->seg[s] = g;
+    }
+    return 0;
+}
+
+}  // namespace
+
+static WStride mk_stride(const int64_t* st) { return WStride{st[0], st[1], st[2], st[3]}; }
+
+// strides[4] = element strides of Wl over (group, j, channel, site)
+DD3D_API int dd3d_sparse_linear_fwd(const float* F, const int32_t* site, const int32_t* seg_off, int B, int C, const int32_t* cloud_group,
+                                    const float* Wl, const int64_t* strides, int J, const float* bias, float* out, void* stream) {
+    if (B < 0 || C != 128 || J <= 0 || !strides) return DD3D_EARG;
+    if (B == 0) return 0;
+    if (!F || !site || !seg_off || !Wl || !out) return DD3D_EARG;
+    k_sl_fwd<<<dim3(B), 256, 0, (hipStream_t)stream>>>(F, site, seg_off, cloud_group, Wl, mk_stride(strides), J, bias, out);
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}
+
+DD3D_API int dd3d_sparse_linear_bwd_x(const float* dl, const int32_t* site, const int32_t* seg_off, int B, int C, const int32_t* cloud_group,
+                                      const float* Wl, const int64_t* strides, int J, int accumulate, float* dF, void* stream) {
+    if (B < 0 || C != 128 || J <= 0 || J > 8192 || !strides) return DD3D_EARG;
+    if (B == 0) return 0;
+    if (!dl || !site || !seg_off || !Wl || !dF) return DD3D_EARG;
+    k_sl_bwd_x<<<dim3(B), 256, J * sizeof(float), (hipStream_t)stream>>>(dl, site, seg_off, cloud_group, Wl, mk_stride(strides), J, accumulate, dF);
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}
+
+// dWl must hold G * strides[0] floats (or J*C*S when G == 1); it is zero-filled here, then the occupied sites are written.
+DD3D_API int dd3d_sparse_linear_bwd_w(const float* dl, const float* F, const int32_t* vox_at, int S, const int32_t* group_cloud_off, int G, int C, int J,
+                                      float* dWl, const int64_t* strides, int64_t dWl_elems, void* stream) {
+    if (G <= 0 || C != 128 || J <= 0 || S <= 0 || !strides || !dWl || !group_cloud_off || dWl_elems < (int64_t)J * C * S) return DD3D_EARG;
+    hipStream_t st = (hipStream_t)stream;
+    DD3D_HIP(hipMemsetAsync(dWl, 0, dWl_elems * 4, st));
+    if (!dl || !F || !vox_at) return DD3D_EARG;
+    k_sl_bwd_w<<<dim3(S, G), 128, 0, st>>>(dl, F, vox_at, S, group_cloud_off, J, dWl, mk_stride(strides));
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}
+
+// cloud_loss[B] is scratch; loss_g[G] (may be null) receives the mean CE of every group
+DD3D_API int dd3d_softmax_ce(const float* logits, const int32_t* labels, const int32_t* cloud_group, const int32_t* group_cloud_off, int G, int B, int J,
+                             float* prob, float* dlogits, float* cloud_loss, float* loss_g, void* stream) {
+    if (G <= 0 || J <= 0 || B < 0 || !group_cloud_off) return DD3D_EARG;
+    if (B == 0) return 0;
+    if (!logits || !labels || !dlogits || !cloud_loss) return DD3D_EARG;
+    hipStream_t st = (hipStream_t)stream;
+    k_softmax_ce<<<dim3((B + 63) / 64), 64, 0, st>>>(logits, labels, cloud_group, group_cloud_off, B, J, prob, dlogits, cloud_loss);
+    if (loss_g) k_group_sum<<<dim3((G + 63) / 64), 64, 0, st>>>(cloud_loss, group_cloud_off, G, loss_g);
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}
+
+DD3D_API int dd3d_softmax_ce_bwd2(const float* prob, const float* u, const int32_t* group_cloud_off, int G, int J, int max_clouds_per_group, float* dz,
+                                  void* stream) {
+    if (G <= 0 || J <= 0 || max_clouds_per_group <= 0 || !prob || !u || !group_cloud_off || !dz) return DD3D_EARG;
+    k_softmax_ce_bwd2<<<dim3((max_clouds_per_group + 63) / 64, G), 64, 0, (hipStream_t)stream>>>(prob, u, group_cloud_off, G, J, dz);
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}
+
+DD3D_API int64_t dd3d_match_loss_ws_bytes(const dd3d_gseg* segs, int n) {
+    GPlan p;
+    if (build_plan(segs, n, 0, &p)) return -1;
+    return align_up64((int64_t)p.part_off[n] * 16, 256) + 256;
+}
+
+DD3D_API int64_t dd3d_match_loss_stats_floats(const dd3d_gseg* segs, int n) {
+    GPlan p;
+    if (build_plan(segs, n, 0, &p)) return -1;
+    return ((int64_t)p.row_off[n] + 1) * 4;
+}
+
+// metric: 0 'ours' (distance_wb), 1 'modmse' (distance_mse), 2 'mse', 3 'cos'.  segs is a HOST array.
+DD3D_API int dd3d_match_loss_fwd(const dd3d_gseg* segs, int n, int metric, float* loss_dev, float* stats_dev, void* ws, int64_t ws_bytes, void* stream) {
+    GPlan p;
+    int rc = build_plan(segs, n, metric, &p);
+    if (rc) return rc;
+    if (!loss_dev || !stats_dev) return DD3D_EARG;
+    if (!ws || ws_bytes < dd3d_match_loss_ws_bytes(segs, n)) return DD3D_EWS;
+    hipStream_t st = (hipStream_t)stream;
+    float4* partial = (float4*)ws;
+    k_gd_stats<<<dim3(p.item_off[n]), 256, 0, st>>>(p, partial);
+    k_gd_finalize<<<1, 256, 0, st>>>(p, partial, (float4*)stats_dev, loss_dev);
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}
+
+// writes seg[i].dsyn (where non-null) = gl * d loss / d seg[i].syn ; gl_dev may be null (= 1)
+DD3D_API int dd3d_match_loss_bwd(const dd3d_gseg* segs, int n, int metric, const float* stats_dev, const float* gl_dev, void* ws, int64_t ws_bytes,
+                                 void* stream) {
+    GPlan p;
+    int rc = build_plan(segs, n, metric, &p);
+    if (rc) return rc;
+    if (!stats_dev) return DD3D_EARG;
+    (void)ws; (void)ws_bytes;
+    hipStream_t st = (hipStream_t)stream;
+    k_gd_bwd<<<dim3(p.item_off[n]), 256, 0, st>>>(p, (const float4*)stats_dev, gl_dev);
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}
+
+DD3D_API int dd3d_sgd_momentum_clamp(float* x, const float* grad, float* mom, int64_t n, float lr, float momentum, int first_step, int do_clamp, float lo,
+                                     float hi, void* stream) {
+    if (n < 0) return DD3D_EARG;
+    if (n == 0) return 0;
+    if (!x || !grad || !mom) return DD3D_EARG;
+    k_sgd_clamp<<<dim3((unsigned)ceil_div64(n, 256)), 256, 0, (hipStream_t)stream>>>(x, grad, mom, n, lr, momentum, first_step, do_clamp, lo, hi);
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,301 @@
+// Bandwidth-bound feature kernels: voxel mean (TensorField.sparse()), instance norm (N7), and the fused
+// affine + ReLU + max-pool (N7 affine, N8, N9) with their backward passes.  C (channels) is 128 for the norm/pool kernels:
+// one row = 512 B = 32 lanes x float4, so every row access is a fully coalesced 512-B segment.
+#include "common.h"
+
+namespace {
+
+// ---- voxel mean -----------------------------------------------------------------------------
+__global__ void k_voxel_mean_fwd(const float* __restrict__ feats, int C, const int* __restrict__ vox_off, const int* __restrict__ vox_pts, int64_t M,
+                                 float* __restrict__ F0) {
+    int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= M * C) return;
+    int64_t v = t / C;
+    int c = (int)(t - v * C);
+    int a = vox_off[v], b = vox_off[v + 1];
+    float s = 0.f;
+    for (int j = a; j < b; ++j) s += feats[(int64_t)vox_pts[j] * C + c];  // ascending point order: deterministic
+    F0[t] = s / (float)(b - a);
+}
+
+__global__ void k_voxel_mean_bwd(const float* __restrict__ dF0, int C, const int* __restrict__ inv, const int* __restrict__ vox_off, int64_t N,
+                                 float* __restrict__ dfeats) {
+    int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= N * C) return;
+    int64_t p = t / C;
+    int c = (int)(t - p * C);
+    int v = inv[p];
+    dfeats[t] = dF0[(int64_t)v * C + c] / (float)(vox_off[v + 1] - vox_off[v]);
+}
+
+// ---- instance norm: one workgroup per cloud, 8 row-lanes x 32 float4 channel-lanes -----------
+__device__ __forceinline__ f32x4 block_colsum(f32x4 v, f32x4* s_red /*[8*32]*/) {
+    const int c4 = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    s_red[rl * 32 + c4] = v;
+    __syncthreads();
+    f32x4 s = s_red[c4];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) s += s_red[j * 32 + c4];
+    __syncthreads();
+    return s;
+}
+
+__global__ __launch_bounds__(256) void k_inorm_fwd(const f32x4* __restrict__ Y, const int* __restrict__ seg_off, f32x4* __restrict__ xhat,
+                                                   f32x4* __restrict__ inv_std) {
+    __shared__ f32x4 s_red[256];
+    const int b = blockIdx.x, c4 = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int r0 = seg_off[b], r1 = seg_off[b + 1];
+    const int n = r1 - r0;
+    if (n <= 0) {
+        if (rl == 0) inv_std[(int64_t)b * 32 + c4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        return;
+    }
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int r = r0 + rl; r < r1; r += 8) s += Y[(int64_t)r * 32 + c4];
+    f32x4 mean = block_colsum(s, s_red) / (float)n;
+    f32x4 q = {0.f, 0.f, 0.f, 0.f};
+    for (int r = r0 + rl; r < r1; r += 8) {
+        f32x4 d = Y[(int64_t)r * 32 + c4] - mean;
+        q += d * d;
+    }
+    f32x4 var = block_colsum(q, s_red) / (float)n;
+    f32x4 is;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) is[j] = 1.0f / sqrtf(var[j] + 1e-8f);
+    if (rl == 0) inv_std[(int64_t)b * 32 + c4] = is;
+    for (int r = r0 + rl; r < r1; r += 8) xhat[(int64_t)r * 32 + c4] = (Y[(int64_t)r * 32 + c4] - mean) * is;
+}
+
+// dY = (g - xhat * mean(g*xhat) - mean(g)) * inv_std     (MinkowskiInstanceNormFunction.backward)
+__global__ __launch_bounds__(256) void k_inorm_bwd(const f32x4* __restrict__ g, const f32x4* __restrict__ xhat, const f32x4* __restrict__ inv_std,
+                                                   const int* __restrict__ seg_off, f32x4* __restrict__ dY) {
+    __shared__ f32x4 s_red[256];
+    const int b = blockIdx.x, c4 = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int r0 = seg_off[b], r1 = seg_off[b + 1];
+    const int n = r1 - r0;
+    if (n <= 0) return;
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    for (int r = r0 + rl; r < r1; r += 8) {
+        f32x4 gg = g[(int64_t)r * 32 + c4];
+        s1 += gg;
+        s2 += gg * xhat[(int64_t)r * 32 + c4];
+    }
+    f32x4 m1 = block_colsum(s1, s_red) / (float)n;
+    f32x4 m2 = block_colsum(s2, s_red) / (float)n;
+    f32x4 is = inv_std[(int64_t)b * 32 + c4];
+    for (int r = r0 + rl; r < r1; r += 8) {
+        int64_t o = (int64_t)r * 32 + c4;
+        dY[o] = (g[o] - xhat[o] * m2 - m1) * is;
+    }
+}
+
+// ---- fused affine + ReLU + max-pool (k=2, s=2) ------------------------------------------------
+// out[o][c] = max over existing children i of relu(xhat[i][c]*w[c]+b[c]); first maximum in offset order wins; arg = child row
+__global__ __launch_bounds__(256) void k_arp_fwd(const f32x4* __restrict__ xhat, const f32x4* __restrict__ w, const f32x4* __restrict__ bias,
+                                                 int use_affine_relu, const int* __restrict__ kids, int64_t ld, int Kp, int64_t M_out,
+                                                 f32x4* __restrict__ out, int4* __restrict__ arg) {
+    const int c4 = threadIdx.x & 31;
+    int64_t o = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (o >= M_out) return;
+    f32x4 ww = {1.f, 1.f, 1.f, 1.f}, bb = {0.f, 0.f, 0.f, 0.f};
+    if (use_affine_relu) {
+        ww = w[c4];
+        bb = bias[c4];
+    }
+    const float ninf = -__builtin_inff();
+    f32x4 best = {ninf, ninf, ninf, ninf};
+    int4 a = make_int4(-1, -1, -1, -1);
+    for (int k = 0; k < Kp; ++k) {
+        int i = kids[(int64_t)k * ld + o];
+        if (i < 0) continue;
+        f32x4 v = xhat[(int64_t)i * 32 + c4];
+        if (use_affine_relu) {
+            v = v * ww + bb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        if (v[0] > best[0]) { best[0] = v[0]; a.x = i; }
+        if (v[1] > best[1]) { best[1] = v[1]; a.y = i; }
+        if (v[2] > best[2]) { best[2] = v[2]; a.z = i; }
+        if (v[3] > best[3]) { best[3] = v[3]; a.w = i; }
+    }
+    out[o * 32 + c4] = best;
+    arg[o * 32 + c4] = a;
+}
+
+// Backward of pool -> ReLU -> affine for every INPUT row i (each has exactly one parent):
+//   gy = (arg[parent[i]] == i) ? g_pool[parent[i]] : 0 ; ga = (xhat*w+b > 0) ? gy : 0 ; g_xhat = ga * w
+//   per row-chunk partial sums of ga*xhat (-> d weight) and ga (-> d bias); optional ga_out and an optional extra term
+//   g_xhat += ga_prev * gw_extra[group]   (second-order term of the matching loss through the affine weight gradient)
+__global__ __launch_bounds__(256) void k_arp_bwd(const f32x4* __restrict__ g_pool, const int4* __restrict__ arg, const int* __restrict__ parent,
+                                                 const f32x4* __restrict__ xhat, const f32x4* __restrict__ w, const f32x4* __restrict__ bias,
+                                                 int use_affine_relu, const int* __restrict__ group_row_off, int G, int CH,
+                                                 f32x4* __restrict__ g_xhat, f32x4* __restrict__ ga_out, const f32x4* __restrict__ ga_prev,
+                                                 const f32x4* __restrict__ gw_extra, f32x4* __restrict__ partial /*[slots][2][32]*/,
+                                                 int* __restrict__ slab_valid) {
+    __shared__ f32x4 s_red[256];
+    const int c4 = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    int g, r0, r1;
+    if (!resolve_chunk(blockIdx.x, group_row_off, G, CH, &g, &r0, &r1)) return;
+    f32x4 ww = {1.f, 1.f, 1.f, 1.f}, bb = {0.f, 0.f, 0.f, 0.f};
+    if (use_affine_relu) {
+        ww = w[c4];
+        bb = bias[c4];
+    }
+    f32x4 ex = {0.f, 0.f, 0.f, 0.f};
+    if (gw_extra) ex = gw_extra[(int64_t)g * 32 + c4];
+    f32x4 sw = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+    for (int i = r0 + rl; i < r1; i += 8) {
+        int p = parent[i];
+        int64_t po = (int64_t)p * 32 + c4, io = (int64_t)i * 32 + c4;
+        int4 a = arg[po];
+        f32x4 gp = g_pool[po];
+        f32x4 xh = xhat[io];
+        f32x4 ga;
+        ga[0] = a.x == i ? gp[0] : 0.f;
+        ga[1] = a.y == i ? gp[1] : 0.f;
+        ga[2] = a.z == i ? gp[2] : 0.f;
+        ga[3] = a.w == i ? gp[3] : 0.f;
+        if (use_affine_relu) {
+            f32x4 y = xh * ww + bb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ga[j] = y[j] > 0.f ? ga[j] : 0.f;
+        }
+        sw += ga * xh;
+        sb += ga;
+        f32x4 gx = ga * ww;
+        if (ga_prev) gx += ga_prev[io] * ex;
+        g_xhat[io] = gx;
+        if (ga_out) ga_out[io] = ga;
+    }
+    f32x4 tw = block_colsum(sw, s_red);
+    f32x4 tb = block_colsum(sb, s_red);
+    if (partial && rl == 0) {
+        partial[((int64_t)blockIdx.x * 2 + 0) * 32 + c4] = tw;
+        partial[((int64_t)blockIdx.x * 2 + 1) * 32 + c4] = tb;
+        if (c4 == 0) slab_valid[blockIdx.x] = 1;
+    }
+}
+
+// out[g][j][c4] = sum over the chunk slots of group g, slot order (deterministic); j in {0: d weight, 1: d bias}
+__global__ void k_arp_reduce(const f32x4* __restrict__ partial, const int* __restrict__ slab_valid, const int* __restrict__ group_row_off, int G, int CH,
+                             f32x4* __restrict__ gw_w, f32x4* __restrict__ gw_b) {
+    const int g = blockIdx.x, c4 = threadIdx.x & 31, j = threadIdx.x >> 5;  // 64 threads
+    int first = 0;
+    for (int q = 0; q < g; ++q) first += (group_row_off[q + 1] - group_row_off[q] + CH - 1) / CH;
+    int n = (group_row_off[g + 1] - group_row_off[g] + CH - 1) / CH;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int c = first; c < first + n; ++c)
+        if (slab_valid[c]) s += partial[((int64_t)c * 2 + j) * 32 + c4];
+    (j == 0 ? gw_w : gw_b)[(int64_t)g * 32 + c4] = s;
+}
+
+// g_xhat[i] = ga[i] * gw[group(i)]  (outer-backward seed through an affine weight gradient)
+__global__ void k_scale_rows_by_group(const f32x4* __restrict__ ga, const f32x4* __restrict__ gw, const int* __restrict__ group_row_off, int G,
+                                      int64_t M, f32x4* __restrict__ out) {
+    const int c4 = threadIdx.x & 31;
+    int64_t i = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (i >= M) return;
+    int g = 0;
+    while (g + 1 < G && i >= group_row_off[g + 1]) ++g;
+    out[i * 32 + c4] = ga[i * 32 + c4] * gw[(int64_t)g * 32 + c4];
+}
+
+int arp_chunk(int64_t M) {
+    int64_t ch = align_up64(ceil_div64(M > 0 ? M : 1, 2048), 8);
+    if (ch < 64) ch = 64;
+    return (int)ch;
+}
+
+}  // namespace
+
+DD3D_API int dd3d_voxel_mean_fwd(const float* feats, int64_t N, int C, const int32_t* vox_off, const int32_t* vox_pts, int64_t M, float* F0,
+                                 void* stream) {
+    if (N < 0 || M < 0 || C <= 0) return DD3D_EARG;
+    if (M == 0) return 0;
+    if (!feats || !vox_off || !vox_pts || !F0) return DD3D_EARG;
+    k_voxel_mean_fwd<<<dim3((unsigned)ceil_div64(M * C, 256)), 256, 0, (hipStream_t)stream>>>(feats, C, vox_off, vox_pts, M, F0);
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}
+
+DD3D_API int dd3d_voxel_mean_bwd(const float* dF0, int64_t M, int C, const int32_t* inv, const int32_t* vox_off, int64_t N, float* dfeats,
+                                 void* stream) {
+    if (N < 0 || M < 0 || C <= 0) return DD3D_EARG;
+    if (N == 0) return 0;
+    if (!dF0 || !inv || !vox_off || !dfeats) return DD3D_EARG;
+    k_voxel_mean_bwd<<<dim3((unsigned)ceil_div64(N * C, 256)), 256, 0, (hipStream_t)stream>>>(dF0, C, inv, vox_off, N, dfeats);
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}
+
+DD3D_API int dd3d_inorm_fwd(const float* Y, const int32_t* seg_off, int B, int C, float* xhat, float* inv_std, void* stream) {
+    if (B < 0 || C != 128) return DD3D_EARG;
+    if (B == 0) return 0;
+    if (!Y || !seg_off || !xhat || !inv_std) return DD3D_EARG;
+    k_inorm_fwd<<<dim3(B), 256, 0, (hipStream_t)stream>>>((const f32x4*)Y, seg_off, (f32x4*)xhat, (f32x4*)inv_std);
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}
+
+DD3D_API int dd3d_inorm_bwd(const float* g, const float* xhat, const float* inv_std, const int32_t* seg_off, int B, int C, float* dY, void* stream) {
+    if (B < 0 || C != 128) return DD3D_EARG;
+    if (B == 0) return 0;
+    if (!g || !xhat || !inv_std || !seg_off || !dY) return DD3D_EARG;
+    k_inorm_bwd<<<dim3(B), 256, 0, (hipStream_t)stream>>>((const f32x4*)g, (const f32x4*)xhat, (const f32x4*)inv_std, seg_off, (f32x4*)dY);
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}
+
+// out[M_out,128], arg[M_out,128] (child row that won).  w/b may be null with use_affine_relu = 0 (plain max-pool).
+DD3D_API int dd3d_affine_relu_pool_fwd(const float* xhat, const float* w, const float* b, int use_affine_relu, int C, const int32_t* kids, int64_t ld,
+                                       int Kp, int64_t M_out, float* out, int32_t* arg, void* stream) {
+    if (M_out < 0 || C != 128 || Kp <= 0 || ld < M_out || (use_affine_relu && (!w || !b))) return DD3D_EARG;
+    if (M_out == 0) return 0;
+    if (!xhat || !kids || !out || !arg) return DD3D_EARG;
+    k_arp_fwd<<<dim3((unsigned)ceil_div64(M_out, 8)), 256, 0, (hipStream_t)stream>>>((const f32x4*)xhat, (const f32x4*)w, (const f32x4*)b, use_affine_relu,
+                                                                                    kids, ld, Kp, M_out, (f32x4*)out, (int4*)arg);
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}
+
+DD3D_API int64_t dd3d_arp_bwd_ws_bytes(int64_t M_in, int G) {
+    int64_t slots = ceil_div64(M_in, arp_chunk(M_in)) + G;
+    return align_up64(slots * 2 * 128 * 4, 256) + align_up64(slots * 4, 256);
+}
+
+// g_xhat[M_in,128]; gw_w/gw_b [G,128] (may be null); ga_out (may be null) saves relu-masked pooled gradient;
+// ga_prev + gw_extra[G,128] (both or neither) add ga_prev * gw_extra[group] to g_xhat.
+DD3D_API int dd3d_affine_relu_pool_bwd(const float* g_pool, const int32_t* arg, const int32_t* parent, const float* xhat, const float* w, const float* b,
+                                       int use_affine_relu, int C, int64_t M_in, const int32_t* group_row_off, int G, float* g_xhat, float* ga_out,
+                                       const float* ga_prev, const float* gw_extra, float* gw_w, float* gw_b, void* ws, int64_t ws_bytes, void* stream) {
+    if (M_in < 0 || C != 128 || G <= 0 || !group_row_off || (use_affine_relu && (!w || !b)) || ((ga_prev == nullptr) != (gw_extra == nullptr)) ||
+        ((gw_w == nullptr) != (gw_b == nullptr)))
+        return DD3D_EARG;
+    if (ws_bytes < dd3d_arp_bwd_ws_bytes(M_in, G) || !ws) return DD3D_EWS;
+    hipStream_t st = (hipStream_t)stream;
+    int CH = arp_chunk(M_in);
+    int64_t slots = ceil_div64(M_in, CH) + G;
+    f32x4* partial = (f32x4*)ws;
+    int* valid = (int*)((char*)ws + align_up64(slots * 2 * 128 * 4, 256));
+    DD3D_HIP(hipMemsetAsync(valid, 0, slots * 4, st));
+    if (M_in > 0) {
+        if (!g_pool || !arg || !parent || !xhat || !g_xhat) return DD3D_EARG;
+        k_arp_bwd<<<dim3((unsigned)slots), 256, 0, st>>>((const f32x4*)g_pool, (const int4*)arg, parent, (const f32x4*)xhat, (const f32x4*)w,
+                                                         (const f32x4*)b, use_affine_relu, group_row_off, G, CH, (f32x4*)g_xhat, (f32x4*)ga_out,
+                                                         (const f32x4*)ga_prev, (const f32x4*)gw_extra, gw_w ? partial : nullptr, valid);
+    }
+    if (gw_w) k_arp_reduce<<<dim3(G), 64, 0, st>>>(partial, valid, group_row_off, G, CH, (f32x4*)gw_w, (f32x4*)gw_b);
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}
+
+DD3D_API int dd3d_scale_rows_by_group(const float* ga, const float* gw, const int32_t* group_row_off, int G, int64_t M, int C, float* out, void* stream) {
+    if (M < 0 || C != 128 || G <= 0 || !group_row_off) return DD3D_EARG;
+    if (M == 0) return 0;
+    if (!ga || !gw || !out) return DD3D_EARG;
+    k_scale_rows_by_group<<<dim3((unsigned)ceil_div64(M, 8)), 256, 0, (hipStream_t)stream>>>((const f32x4*)ga, (const f32x4*)gw, group_row_off, G, M,
+                                                                                            (f32x4*)out);
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,121 @@
+"""The gradient-matching loop of the reference's ``mnist_distill.py`` (:294-374) on the MI355X kernels.
+
+``Distiller.outer_step()`` is one iteration of the reference loop without evaluation / logging / export (SURVEY.md section 8a
+row a1): clamp (:311-317), per-class real and synthetic forward + gradients (:335-359), ``match_loss`` (:360), backward into the
+synthetic xyz (:365) and the SGD(momentum 0.5) step (:369).  Run as a script it takes the reference's flags
+(``--log/--no-log --exp --pytorch``) and INI keys, on MNIST-shaped synthetic digits (no dataset download offline).
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .configs import settings
+from .distillation_loss import match_loss
+from .models.MEConv import MEConvExp, MEPytorch, create_input_batch
+from .utils.Mnist2D import Mnist2Dsyn, batch_from_images, get_mnist_dataloader
+
+
+class Distiller:
+    def __init__(self, images_all, indices_class, network, ipc, num_classes=10, num_points=250, batch_size=256, dist_opt="modmse",
+                 dist_lr=0.1, device=None, seed=0, image_syn=None):
+        self.device = torch.device(device or settings.device)
+        self.images_all = images_all.to(self.device)
+        self.indices_class = [np.asarray(ix) for ix in indices_class]
+        self.network = network.to(self.device).train()
+        self.net_parameters = list(self.network.parameters())
+        self.num_classes, self.ipc, self.num_points, self.batch_size = num_classes, ipc, num_points, batch_size
+        self.dist_opt, self.rng = dist_opt, np.random.RandomState(seed)
+        settings.num_points, settings.cad_per_class = num_points, ipc
+        if image_syn is None:  # :295-299
+            g = torch.Generator().manual_seed(seed)
+            image_syn = 28 * torch.rand((num_classes * ipc, num_points, 3), generator=g, dtype=torch.float)
+        self.image_syn = image_syn.to(self.device).clone()
+        self.label_syn = torch.arange(num_classes, device=self.device).repeat_interleave(ipc)
+        self.criterion = nn.CrossEntropyLoss().to(self.device)
+        self.optimizer_img = torch.optim.SGD([self.image_syn], lr=dist_lr, momentum=0.5)  # :303
+        self.last = {}
+
+    # -- mnist_distill.py:311-317
+    def clamp(self):
+        s = self.image_syn
+        s.requires_grad_(False)
+        s[s < 0] = 0
+        s[s > 27] = 27
+        s[:, :, 0] = 0
+        s.requires_grad_()
+
+    # -- mnist_distill.py:200-208 (the dataset + dataloader + collate chain collapsed into one device-side gather)
+    def get_images(self, c, n):
+        idx = self.rng.permutation(self.indices_class[c])[:n]
+        img_real = self.images_all[torch.as_tensor(idx, device=self.device)]
+        labels = torch.full((img_real.shape[0],), c, device=self.device, dtype=torch.long)
+        return batch_from_images(img_real, labels, self.num_points)
+
+    # -- mnist_distill.py:241-249
+    def synthetic_batch(self, c):
+        img_syn = self.image_syn[c * self.ipc:(c + 1) * self.ipc]
+        lab_syn = torch.full((self.ipc,), c, device=self.device, dtype=torch.long)
+        (batch,) = list(get_mnist_dataloader(Mnist2Dsyn(img_syn, lab_syn, False), self.ipc))
+        return batch
+
+    def class_loss(self, c, real_batch=None):
+        """mnist_distill.py:336-360 for one class; returns (matched_loss, gw_real, gw_syn)."""
+        net, dev = self.network, self.device
+        batch = real_batch if real_batch is not None else self.get_images(c, self.batch_size)
+        output = net(create_input_batch(batch, True, device=dev, quantization_size=1))
+        loss_real = self.criterion(output, batch["labels"])
+        gw_real = [g.detach().clone() for g in torch.autograd.grad(loss_real, self.net_parameters)]
+        sbatch = self.synthetic_batch(c)
+        output_s = net(create_input_batch(sbatch, True, device=dev, quantization_size=1))
+        loss_syn = self.criterion(output_s, sbatch["labels"])
+        gw_syn = torch.autograd.grad(loss_syn, self.net_parameters, create_graph=True)
+        self.last.setdefault("logits", []).append((output.detach(), output_s.detach()))
+        return match_loss(gw_syn, gw_real, self.dist_opt, dev), gw_real, gw_syn
+
+    def outer_step(self, real_batches=None, apply_update=True):
+        """One iteration of mnist_distill.py:309-374 (no evaluation / logging / export).  Returns the summed matching loss (0-d,
+        on the device, no host sync)."""
+        self.clamp()
+        self.last = {"per_class": [], "gw_real": [], "gw_syn": []}
+        loss = torch.zeros((), device=self.device)
+        for c in range(self.num_classes):
+            m, gwr, gws = self.class_loss(c, None if real_batches is None else real_batches[c])
+            loss = loss + m
+            self.last["per_class"].append(m.detach())
+            self.last["gw_real"].append(gwr)
+            self.last["gw_syn"].append([g.detach() for g in gws])
+        self.optimizer_img.zero_grad()
+        loss.backward()
+        self.last["grad"] = self.image_syn.grad.detach().clone()
+        if apply_update:
+            self.optimizer_img.step()
+        return loss.detach()
+
+
+def main(argv=None):
+    from .synthetic import mnist3d_like
+    settings.init(argv)
+    dev = settings.device
+    torch.random.manual_seed(int(time.time() * 1000) % 100000)
+    images_all, _labels, indices_class = mnist3d_like(10, 512, seed=0)
+    network = MEPytorch(3, 10) if settings.Pyt else MEConvExp(in_channel=3, out_channel=10)
+    settings.log_string(network)
+    d = Distiller(images_all, indices_class, network, ipc=settings.cad_per_class, num_points=settings.num_points,
+                  batch_size=settings.modelconfig.getint("batch_size"), dist_opt=settings.modelconfig.get("dist_opt"),
+                  dist_lr=settings.modelconfig.getfloat("dist_lr"), device=dev)
+    total = settings.distillationconfig.getint("total_iterations")
+    log_loss = []
+    for iteration in range(total):
+        loss = d.outer_step()
+        log_loss.append(loss.item() / 10)
+        if iteration % 100 == 0:
+            settings.log_string("Iteration: %d Loss matched is %s" % (iteration, sum(log_loss) / len(log_loss)))
+            log_loss = []
+
+
+if __name__ == "__main__":
+    main()

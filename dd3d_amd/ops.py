@@ -1,0 +1,328 @@
+"""torch.autograd wrappers around libdd3d_hip.so -- one Function per MinkowskiEngine op family on the hot path.
+
+Second-order semantics.  The reference differentiates ``torch.autograd.grad(loss_syn, params,
+create_graph=True)`` again (mnist_distill.py:359,365).  MinkowskiEngine's Functions have native backward passes, so what comes out
+of them under ``create_graph=True`` is a constant; only the torch-native pieces (instance-norm affine, ReLU, dense()/Linear/CE) are
+differentiated twice.  The Functions below reproduce exactly that: the backward of every sparse op calls a HIP kernel on raw
+buffers (its results carry no graph), while
+
+  * ``NormActPoolFn`` keeps the one second-order path that exists inside a block,
+    d(sum_rows ga * xhat)/dxhat, by routing its backward through ``_NormActPoolBwdFn`` (a Function with its own backward);
+  * the classifier (``SparseLinearFn`` and friends) is closed under differentiation, like index_put + addmm in the reference.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch.autograd import Function
+
+from . import _lib as L
+from .sparse import CoordinateManager
+
+_F32 = torch.float32
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    t = t.detach()
+    if t.dtype != _F32:
+        raise RuntimeError("dd3d_amd kernels compute in fp32")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ----------------------------------------------------------------------------------------------- voxel mean
+class VoxelMeanFn(Function):
+    """F0[v] = mean of the features of voxel v's points (MinkowskiSPMMAverageFunction inside TensorField.sparse())."""
+
+    @staticmethod
+    def forward(ctx, feats, cm: CoordinateManager):
+        M = cm.num_rows(1)
+        f = _c(feats)
+        N, Cf = f.shape
+        out = torch.empty((M, Cf), dtype=_F32, device=f.device)
+        L.call("dd3d_voxel_mean_fwd", L.ptr(f), N, Cf, L.ptr(cm.vox_off), L.ptr(cm.vox_pts), M, L.ptr(out), L.stream())
+        ctx.cm, ctx.N, ctx.Cf = cm, N, Cf
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        cm = ctx.cm
+        g = _c(g)
+        d = torch.empty((ctx.N, ctx.Cf), dtype=_F32, device=g.device)
+        L.call("dd3d_voxel_mean_bwd", L.ptr(g), g.shape[0], ctx.Cf, L.ptr(cm.levels[1].inv), L.ptr(cm.vox_off), ctx.N, L.ptr(d), L.stream())
+        return d, None
+
+
+def voxel_mean(feats, cm):
+    return VoxelMeanFn.apply(feats, cm)
+
+
+# ----------------------------------------------------------------------------------------------- convolution
+_wt_cache = {}
+
+
+def transposed_kernel(W: torch.Tensor) -> torch.Tensor:
+    """Wt[k][co][ci] for the backward-data pass, cached per (storage, version)."""
+    key = (W.data_ptr(), W._version, tuple(W.shape))
+    hit = _wt_cache.get(W.data_ptr())
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    K, Cin, Cout = W.shape
+    Wt = torch.empty((K, Cout, Cin), dtype=_F32, device=W.device)
+    L.call("dd3d_transpose_kernel", L.ptr(_c(W)), K, Cin, Cout, L.ptr(Wt), L.stream())
+    if len(_wt_cache) > 64:
+        _wt_cache.clear()
+    _wt_cache[W.data_ptr()] = (key, Wt)
+    return Wt
+
+
+def _single_group(M: int, device) -> torch.Tensor:
+    return torch.tensor([0, M], dtype=torch.int32, device=device)
+
+
+def conv_bwd_weight(X, dY, nbr, ld, M_out, group_row_off, G):
+    K, Cin, Cout = nbr.shape[0], X.shape[1], dY.shape[1]
+    dW = torch.empty((G, K, Cin, Cout), dtype=_F32, device=X.device)
+    ws = L.workspace(int(L.lib.dd3d_conv_bwd_weight_ws_bytes(M_out, G, K, Cin, Cout)), X.device)
+    L.call("dd3d_conv_bwd_weight", L.ptr(X), Cin, L.ptr(dY), Cout, L.ptr(nbr), ld, K, M_out, L.ptr(group_row_off), G, L.ptr(dW),
+           L.ptr(ws), ws.numel(), L.stream())
+    return dW
+
+
+class SparseConvFn(Function):
+    """ME.MinkowskiConvolution(kernel_size=3, stride=1, bias=False): Y[o] = sum_k X[nbr[k][o]] @ W[k]."""
+
+    @staticmethod
+    def forward(ctx, X, W, nbr, ld, M_out):
+        x, w = _c(X), _c(W)
+        K, Cin, Cout = w.shape
+        Y = torch.empty((M_out, Cout), dtype=_F32, device=x.device)
+        L.call("dd3d_conv_fwd", L.ptr(x), x.shape[0], Cin, L.ptr(w), Cout, L.ptr(nbr), ld, K, M_out, 0, L.ptr(Y), L.stream())
+        ctx.save_for_backward(X, W)
+        ctx.nbr, ctx.ld, ctx.M_out = nbr, ld, M_out
+        return Y
+
+    @staticmethod
+    def backward(ctx, g):
+        X, W = ctx.saved_tensors
+        x, w, g = _c(X), _c(W), _c(g)
+        K, Cin, Cout = w.shape
+        dX = dW = None
+        if ctx.needs_input_grad[0]:
+            dX = torch.empty_like(x)
+            wk = transposed_kernel(W) if Cin == 128 else w
+            L.call("dd3d_conv_bwd_data", L.ptr(g), x.shape[0], Cout, L.ptr(wk), Cin, L.ptr(ctx.nbr), ctx.ld, K, L.ptr(dX), L.stream())
+        if ctx.needs_input_grad[1]:
+            dW = conv_bwd_weight(x, g, ctx.nbr, ctx.ld, ctx.M_out, _single_group(ctx.M_out, x.device), 1)[0]
+        return dX, dW, None, None, None
+
+
+# ----------------------------------------------------------------------------------------------- instance norm (stand-alone)
+class InstanceNormFn(Function):
+    """MinkowskiInstanceNormFunction: per cloud and channel, biased variance, eps = 1e-8 inside the sqrt."""
+
+    @staticmethod
+    def forward(ctx, Y, seg_off, B):
+        y = _c(Y)
+        xhat = torch.empty_like(y)
+        inv_std = torch.empty((B, y.shape[1]), dtype=_F32, device=y.device)
+        L.call("dd3d_inorm_fwd", L.ptr(y), L.ptr(seg_off), B, y.shape[1], L.ptr(xhat), L.ptr(inv_std), L.stream())
+        ctx.saved = (xhat, inv_std, seg_off, B)
+        return xhat
+
+    @staticmethod
+    def backward(ctx, g):
+        xhat, inv_std, seg_off, B = ctx.saved
+        g = _c(g)
+        dY = torch.empty_like(g)
+        L.call("dd3d_inorm_bwd", L.ptr(g), L.ptr(xhat), L.ptr(inv_std), L.ptr(seg_off), B, g.shape[1], L.ptr(dY), L.stream())
+        return dY, None, None
+
+
+# ----------------------------------------------------------------------------------------------- max pool (stand-alone)
+def _arp_bwd(g_pool, arg, parent, xhat, w, b, use_ar, group_row_off, G, want_gw, want_ga, ga_prev=None, gw_extra=None):
+    M_in, C = xhat.shape
+    dev = xhat.device
+    g_xhat = torch.empty_like(xhat)
+    ga = torch.empty_like(xhat) if want_ga else None
+    gw_w = torch.empty((G, C), dtype=_F32, device=dev) if want_gw else None
+    gw_b = torch.empty((G, C), dtype=_F32, device=dev) if want_gw else None
+    ws = L.workspace(int(L.lib.dd3d_arp_bwd_ws_bytes(M_in, G)), dev)
+    L.call("dd3d_affine_relu_pool_bwd", L.ptr(g_pool), L.ptr(arg), L.ptr(parent), L.ptr(xhat), L.ptr(w), L.ptr(b), int(use_ar), C, M_in,
+           L.ptr(group_row_off), G, L.ptr(g_xhat), L.ptr(ga), L.ptr(ga_prev), L.ptr(gw_extra), L.ptr(gw_w), L.ptr(gw_b), L.ptr(ws), ws.numel(),
+           L.stream())
+    return g_xhat, ga, gw_w, gw_b
+
+
+class MaxPoolFn(Function):
+    """ME.MinkowskiMaxPooling(kernel_size=2, stride=2): channel-wise max over the existing children of every output voxel."""
+
+    @staticmethod
+    def forward(ctx, X, kids, ld, parent, M_out):
+        x = _c(X)
+        out = torch.empty((M_out, x.shape[1]), dtype=_F32, device=x.device)
+        arg = torch.empty((M_out, x.shape[1]), dtype=torch.int32, device=x.device)
+        L.call("dd3d_affine_relu_pool_fwd", L.ptr(x), None, None, 0, x.shape[1], L.ptr(kids), ld, kids.shape[0], M_out, L.ptr(out), L.ptr(arg), L.stream())
+        ctx.saved = (arg, parent, x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        arg, parent, x = ctx.saved
+        g_x, _, _, _ = _arp_bwd(_c(g), arg, parent, x, None, None, 0, _single_group(x.shape[0], x.device), 1, False, False)
+        return g_x, None, None, None, None
+
+
+# ----------------------------------------------------------------------------------------------- fused norm + affine + ReLU + pool
+class _NormActPoolBwdFn(Function):
+    """(g_pool, Y, w, b) -> (dY, dw, db).  Its own backward implements the only second-order term of the block:
+    dw = sum_rows ga * xhat depends on Y through xhat (ga is a constant)."""
+
+    @staticmethod
+    def forward(ctx, g_pool, Y, w, b, st):
+        xhat, inv_std, arg, parent, seg_off, B, gro, G = st
+        wq, bq = _c(w).reshape(-1), _c(b).reshape(-1)
+        g_xhat, ga, gw_w, gw_b = _arp_bwd(_c(g_pool), arg, parent, xhat, wq, bq, 1, gro, G, True, True)
+        dY = torch.empty_like(xhat)
+        L.call("dd3d_inorm_bwd", L.ptr(g_xhat), L.ptr(xhat), L.ptr(inv_std), L.ptr(seg_off), B, xhat.shape[1], L.ptr(dY), L.stream())
+        ctx.saved = (ga, xhat, inv_std, seg_off, B, gro, G)
+        ctx.wshape = w.shape
+        ctx.mark_non_differentiable(dY)
+        return dY, gw_w.reshape(w.shape) if G == 1 else gw_w, gw_b.reshape(b.shape) if G == 1 else gw_b
+
+    @staticmethod
+    def backward(ctx, _ggY, ggw, _ggb):
+        ga, xhat, inv_std, seg_off, B, gro, G = ctx.saved
+        if ggw is None:
+            return None, None, None, None, None
+        ggw = _c(ggw).reshape(G, -1)
+        gx = torch.empty_like(xhat)
+        L.call("dd3d_scale_rows_by_group", L.ptr(ga), L.ptr(ggw), L.ptr(gro), G, xhat.shape[0], xhat.shape[1], L.ptr(gx), L.stream())
+        dY = torch.empty_like(xhat)
+        L.call("dd3d_inorm_bwd", L.ptr(gx), L.ptr(xhat), L.ptr(inv_std), L.ptr(seg_off), B, xhat.shape[1], L.ptr(dY), L.stream())
+        return None, dY, None, None, None
+
+
+class NormActPoolFn(Function):
+    """MinkowskiInstanceNorm(128) -> MinkowskiReLU -> MinkowskiMaxPooling(2,2) (models/MEConv.py:225-227) as two kernels."""
+
+    @staticmethod
+    def forward(ctx, Y, w, b, seg_off, B, kids, ld, parent, M_out, gro, G):
+        y = _c(Y)
+        C = y.shape[1]
+        xhat = torch.empty_like(y)
+        inv_std = torch.empty((B, C), dtype=_F32, device=y.device)
+        L.call("dd3d_inorm_fwd", L.ptr(y), L.ptr(seg_off), B, C, L.ptr(xhat), L.ptr(inv_std), L.stream())
+        out = torch.empty((M_out, C), dtype=_F32, device=y.device)
+        arg = torch.empty((M_out, C), dtype=torch.int32, device=y.device)
+        L.call("dd3d_affine_relu_pool_fwd", L.ptr(xhat), L.ptr(_c(w).reshape(-1)), L.ptr(_c(b).reshape(-1)), 1, C, L.ptr(kids), ld, kids.shape[0],
+               M_out, L.ptr(out), L.ptr(arg), L.stream())
+        ctx.save_for_backward(Y, w, b)
+        ctx.st = (xhat, inv_std, arg, parent, seg_off, B, gro, G)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        Y, w, b = ctx.saved_tensors
+        dY, dw, db = _NormActPoolBwdFn.apply(g, Y, w, b, ctx.st)
+        return dY, dw, db, None, None, None, None, None, None, None, None
+
+
+# ----------------------------------------------------------------------------------------------- classifier over the dense placement
+class DensePlacement:
+    """site / vox_at tables of SparseTensor.dense(shape=[B,C,E0,E1,E2], min_coordinate=batch min) for the coarsest level."""
+
+    def __init__(self, cm: CoordinateManager, stride: int, extent, cloud_group=None, G: int = 1, group_cloud_off=None):
+        lv = cm.ensure_level(stride)
+        dev = cm.device
+        self.B, self.G = cm.B, G
+        self.E = tuple(int(e) for e in extent)
+        self.S = self.E[0] * self.E[1] * self.E[2]
+        bound = cm._rows_bound(lv)
+        self.site = torch.empty(max(bound, 1), dtype=torch.int32, device=dev)
+        self.vox_at = torch.empty((max(self.B, 1), self.S), dtype=torch.int32, device=dev)
+        self.gmin = torch.empty((G, 3), dtype=torch.int32, device=dev)
+        self.cloud_group = cloud_group
+        self.group_cloud_off = group_cloud_off if group_cloud_off is not None else torch.tensor([0, self.B], dtype=torch.int32, device=dev)
+        self.seg_off = cm.seg_off(stride)
+        L.call("dd3d_dense_sites", L.ptr(lv.C), cm._count_ptr(lv), bound, L.ptr(cloud_group), G, self.B, stride, self.E[0], self.E[1], self.E[2],
+               L.ptr(self.gmin), L.ptr(self.site), L.ptr(self.vox_at), L.ptr(cm.err), L.stream())
+        cm._synced = False
+
+
+def _param_strides(J, C, S):
+    import ctypes
+    return (ctypes.c_int64 * 4)(J * C * S, C * S, S, 1)
+
+
+class _SLFwd(Function):
+    @staticmethod
+    def forward(ctx, F, Wl, dp: DensePlacement):
+        f, w = _c(F), _c(Wl)
+        J = w.shape[-2] if w.dim() == 3 else w.shape[0]
+        out = torch.empty((dp.B, J), dtype=_F32, device=f.device)
+        L.call("dd3d_sparse_linear_fwd", L.ptr(f), L.ptr(dp.site), L.ptr(dp.seg_off), dp.B, f.shape[1], L.ptr(dp.cloud_group if w.dim() == 3 else None),
+               L.ptr(w), _param_strides(J, f.shape[1], dp.S), J, None, L.ptr(out), L.stream())
+        ctx.save_for_backward(F, Wl)
+        ctx.dp = dp
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        F, Wl = ctx.saved_tensors
+        dF = _SLBwdX.apply(g, Wl, ctx.dp) if ctx.needs_input_grad[0] else None
+        dW = _SLBwdW.apply(g, F, ctx.dp, Wl.dim() == 3) if ctx.needs_input_grad[1] else None
+        return dF, dW, None
+
+
+class _SLBwdX(Function):
+    @staticmethod
+    def forward(ctx, dl, Wl, dp: DensePlacement):
+        d, w = _c(dl), _c(Wl)
+        J = d.shape[1]
+        M = int(dp.seg_off_rows)
+        dF = torch.empty((M, 128), dtype=_F32, device=d.device)
+        L.call("dd3d_sparse_linear_bwd_x", L.ptr(d), L.ptr(dp.site), L.ptr(dp.seg_off), dp.B, 128, L.ptr(dp.cloud_group if w.dim() == 3 else None),
+               L.ptr(w), _param_strides(J, 128, dp.S), J, 0, L.ptr(dF), L.stream())
+        ctx.save_for_backward(dl, Wl)
+        ctx.dp = dp
+        return dF
+
+    @staticmethod
+    def backward(ctx, g):
+        dl, Wl = ctx.saved_tensors
+        d_dl = _SLFwd.apply(g, Wl, ctx.dp) if ctx.needs_input_grad[0] else None
+        d_W = _SLBwdW.apply(dl, g, ctx.dp, Wl.dim() == 3) if ctx.needs_input_grad[1] else None
+        return d_dl, d_W, None
+
+
+class _SLBwdW(Function):
+    @staticmethod
+    def forward(ctx, dl, F, dp: DensePlacement, grouped: bool):
+        d, f = _c(dl), _c(F)
+        J, C = d.shape[1], f.shape[1]
+        G = dp.G if grouped else 1
+        shape = (G, J, C * dp.S) if grouped else (J, C * dp.S)
+        dW = torch.empty(shape, dtype=_F32, device=d.device)
+        gco = dp.group_cloud_off if grouped else dp.whole_batch_off
+        L.call("dd3d_sparse_linear_bwd_w", L.ptr(d), L.ptr(f), L.ptr(dp.vox_at), dp.S, L.ptr(gco), G, C, J, L.ptr(dW), _param_strides(J, C, dp.S),
+               dW.numel(), L.stream())
+        ctx.save_for_backward(dl, F)
+        ctx.dp, ctx.grouped = dp, grouped
+        return dW
+
+    @staticmethod
+    def backward(ctx, g):
+        dl, F = ctx.saved_tensors
+        d_dl = _SLFwd.apply(F, g, ctx.dp) if ctx.needs_input_grad[0] else None
+        d_F = _SLBwdX.apply(dl, g, ctx.dp) if ctx.needs_input_grad[1] else None
+        return d_dl, d_F, None, None
+
+
+def sparse_linear(F: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], dp: DensePlacement) -> torch.Tensor:
+    """logits[B,J] = dense(F).view(B,-1) @ weight.T + bias without materialising the dense tensor (models/MEConv.py:254-256)."""
+    dp.seg_off_rows = F.shape[0]
+    if not hasattr(dp, "whole_batch_off"):
+        dp.whole_batch_off = torch.tensor([0, dp.B], dtype=torch.int32, device=F.device)
+    out = _SLFwd.apply(F, weight, dp)
+    return out + bias if bias is not None else out

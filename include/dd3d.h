@@ -1,0 +1,184 @@
+/* libdd3d_hip.so -- C ABI of the MI355X (gfx950) kernels behind dd3d's gradient-matching step.
+ *
+ * Conventions:
+ *   - every pointer is a DEVICE pointer unless the comment says HOST; the caller owns every buffer;
+ *   - `stream` is a hipStream_t passed as void*; every call is stream-ordered, re-entrant and allocates nothing;
+ *   - variable-size outputs are sized by their bound and the true count is written to a device int (`*_dev`) that the next
+ *     call can read, so a chain of coordinate maps needs no host round trip;
+ *   - scratch comes from the caller: `*_ws_bytes()` gives the size, `ws` must be 256-byte aligned;
+ *   - return value: 0 = ok, < 0 = argument error (-1 bad argument, -2 size out of range, -3 workspace too small),
+ *     > 0 = hipError_t.  Nothing throws, nothing calls exit().
+ *   - feature rows are fp32 row-major; channel count C is 128 wherever stated; coordinates are int32 rows (b, c1, c2, c3).
+ *
+ * "replaces" cites the reference call site (paths relative to kghandour/dd3d) whose MinkowskiEngine / torch work the entry
+ * point takes over.  MinkowskiEngine 0.5.4 itself is a third-party dependency of the reference (environment.yml:278).
+ */
+#ifndef DD3D_H
+#define DD3D_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int dd3d_version(void);
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * (1) coordinate quantisation, voxel hash, kernel maps -- integer work, bit-exact
+ * ------------------------------------------------------------------------------------------------------------------- */
+
+/* power-of-two hash capacity for n keys (>= 2n) and the scratch needed by dd3d_unique_rows */
+int64_t dd3d_table_capacity(int64_t n);
+int64_t dd3d_unique_ws_bytes(int64_t n, int64_t cap);
+
+/* q[N,4] = floor(coords[N,4]).  replaces: the quantisation inside ME.TensorField.sparse(), models/MEConv.py:247,199 */
+int dd3d_floor_coords(const float* coords, int64_t N, int32_t* q, void* stream);
+
+/* q[r] = (b, floor(c/stride)*stride ...) for the first *m_dev (or `bound` if null) rows.
+ * replaces: the stride-2 coordinate map of ME.MinkowskiMaxPooling(kernel_size=2, stride=2), models/MEConv.py:227 */
+int dd3d_stride_coords(const int32_t* C, const int32_t* m_dev, int64_t bound, int stride, int32_t* q, void* stream);
+
+/* Unique rows of q in FIRST-OCCURRENCE order (winner = minimum input row).  Outputs: C[bound,4] (first *count_dev rows valid),
+ * inv[bound] (voxel row of every input row), uidx[bound] (input row of every voxel), table[cap] (coordinate -> voxel row hash,
+ * linear probing, -1 empty; reused by dd3d_kernel_map).  replaces: CoordinateMapManager insert/unique behind x.sparse(),
+ * models/MEConv.py:247 */
+int dd3d_unique_rows(const int32_t* q, const int32_t* n_dev, int64_t bound, int32_t* table, int64_t cap, int32_t* C, int32_t* inv,
+                     int32_t* uidx, int32_t* count_dev, void* ws, int64_t ws_bytes, void* stream);
+
+/* floor + unique in one call (q[N,4] is scratch that receives the floored coordinates) */
+int dd3d_quantize_unique(const float* coords, int64_t N, int32_t* q, int32_t* table, int64_t cap, int32_t* C, int32_t* inv,
+                         int32_t* uidx, int32_t* count_dev, void* ws, int64_t ws_bytes, void* stream);
+
+/* per-voxel point lists, points ascending: vox_off[bound+1], vox_pts[bound] */
+int64_t dd3d_csr_ws_bytes(int64_t n);
+int dd3d_voxel_csr(const int32_t* inv, const int32_t* n_dev, int64_t bound, const int32_t* m_dev, int32_t* vox_off, int32_t* vox_pts,
+                   void* ws, int64_t ws_bytes, void* stream);
+
+/* nbr[K][ld]: row of `keys` found through `table` at Cq[o] + offset_k, or -1.  kernel_size 3: offsets {-1,0,1}*tensor_stride,
+ * k = (d0+1) + 3(d1+1) + 9(d2+1), d0 = first spatial column; kernel_size 2: offsets {0,1}*tensor_stride, k = e0 + 2 e1 + 4 e2.
+ * replaces: CoordinateMapManager.kernel_map behind ME.MinkowskiConvolution(kernel_size=3) and ME.MinkowskiMaxPooling,
+ * models/MEConv.py:224,227 */
+int dd3d_kernel_map(const int32_t* Cq, const int32_t* mq_dev, int64_t bound_q, const int32_t* table, int64_t cap, const int32_t* keys,
+                    int kernel_size, int tensor_stride, int32_t* nbr, int64_t ld, void* stream);
+
+/* canonical pair lists of a neighbour table: grouped by offset, sorted by out_row.  offs[K+1]; in_rows/out_rows hold <= K*bound */
+int64_t dd3d_pairs_ws_bytes(int64_t bound, int K);
+int dd3d_kernel_map_pairs(const int32_t* nbr, int64_t ld, const int32_t* m_dev, int64_t bound, int K, int32_t* in_rows, int32_t* out_rows,
+                          int32_t* offs, void* ws, int64_t ws_bytes, void* stream);
+
+/* seg_off[B+1]: first row of every cloud (rows must be grouped by ascending batch index, else *err_dev |= 1) */
+int dd3d_segment_offsets(const int32_t* C, const int32_t* m_dev, int64_t bound, int B, int32_t* seg_off, int32_t* err_dev, void* stream);
+
+/* Placement used by SparseTensor.dense(shape=[B,128,E0,E1,E2], min_coordinate=batch minimum), models/MEConv.py:250-254:
+ * gmin[G,3] per-group minimum corner, site[v] = flat (E0,E1,E2) index of voxel v, vox_at[B][E0*E1*E2] inverse table (nullable).
+ * cloud_group[B] (nullable = one group).  *err_dev |= 2 if a voxel falls outside the extent (ME raises there). */
+int dd3d_dense_sites(const int32_t* C, const int32_t* m_dev, int64_t bound, const int32_t* cloud_group, int G, int B, int tensor_stride,
+                     int E0, int E1, int E2, int32_t* gmin, int32_t* site, int32_t* vox_at, int32_t* err_dev, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * (2) sparse convolution, gather-GEMM with atomic-free output (fp32 MFMA for Cin = 128)
+ * ------------------------------------------------------------------------------------------------------------------- */
+
+/* Y[M_out,Cout] = sum_k X[nbr[k'][o]] . W[k],  W is [K,Cin,Cout], k' = mirror ? K-1-k : k.  K = 27, Cout = 128, Cin in {3,128}.
+ * replaces: ME.MinkowskiConvolution forward (ConvolutionForwardGPU), models/MEConv.py:224 via :248 */
+int dd3d_conv_fwd(const float* X, int64_t M_in, int Cin, const float* W, int Cout, const int32_t* nbr, int64_t ld, int K, int64_t M_out,
+                  int mirror, float* Y, void* stream);
+
+/* dX[M,Cin] of a stride-1 convolution.  Cin = 128: pass the transposed kernel [K,Cout,Cin]; Cin = 3: pass W itself.
+ * replaces: ConvolutionBackwardGPU (input gradient) reached by torch.autograd.grad / loss.backward, mnist_distill.py:349,359,365 */
+int dd3d_conv_bwd_data(const float* dY, int64_t M, int Cout, const float* W_or_Wt, int Cin, const int32_t* nbr, int64_t ld, int K, float* dX,
+                       void* stream);
+
+/* dW[G,K,Cin,Cout], one kernel gradient per group of rows [group_row_off[g], group_row_off[g+1]) (device array of G+1 ints).
+ * Deterministic: fixed row chunks -> partial slabs -> fixed-order reduction.  replaces: ConvolutionBackwardGPU (kernel gradient) */
+int64_t dd3d_conv_bwd_weight_ws_bytes(int64_t M_out, int G, int K, int Cin, int Cout);
+int dd3d_conv_bwd_weight(const float* X, int Cin, const float* dY, int Cout, const int32_t* nbr, int64_t ld, int K, int64_t M_out,
+                         const int32_t* group_row_off, int G, float* dW, void* ws, int64_t ws_bytes, void* stream);
+
+/* Wt[k][co][ci] = W[k][ci][co] */
+int dd3d_transpose_kernel(const float* W, int K, int Cin, int Cout, float* Wt, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * (3) voxel mean, instance norm, affine + ReLU + max-pool -- bandwidth kernels
+ * ------------------------------------------------------------------------------------------------------------------- */
+
+/* F0[v] = mean of the features of the points of voxel v (ascending point order).  replaces: MinkowskiSPMMAverageFunction inside
+ * TensorField.sparse(), models/MEConv.py:247 -- backward is the only route by which gradient reaches the synthetic xyz */
+int dd3d_voxel_mean_fwd(const float* feats, int64_t N, int C, const int32_t* vox_off, const int32_t* vox_pts, int64_t M, float* F0, void* stream);
+int dd3d_voxel_mean_bwd(const float* dF0, int64_t M, int C, const int32_t* inv, const int32_t* vox_off, int64_t N, float* dfeats, void* stream);
+
+/* xhat = (Y - mean_b) / sqrt(var_b + 1e-8) per cloud b and channel (biased variance); inv_std[B,C].
+ * replaces: MinkowskiInstanceNormFunction forward/backward, models/MEConv.py:225 */
+int dd3d_inorm_fwd(const float* Y, const int32_t* seg_off, int B, int C, float* xhat, float* inv_std, void* stream);
+int dd3d_inorm_bwd(const float* g, const float* xhat, const float* inv_std, const int32_t* seg_off, int B, int C, float* dY, void* stream);
+
+/* out[o] = max over existing children of relu(xhat*w + b) (use_affine_relu = 0: plain max); arg = winning child row.
+ * replaces: the affine of ME.MinkowskiInstanceNorm, ME.MinkowskiReLU and ME.MinkowskiMaxPooling forward, models/MEConv.py:225-227 */
+int dd3d_affine_relu_pool_fwd(const float* xhat, const float* w, const float* b, int use_affine_relu, int C, const int32_t* kids, int64_t ld,
+                              int Kp, int64_t M_out, float* out, int32_t* arg, void* stream);
+
+/* backward of the same three ops for every input row; gw_w/gw_b[G,C] are the per-group affine gradients (nullable pair);
+ * ga_out (nullable) keeps the ReLU-masked pooled gradient; ga_prev + gw_extra[G,C] (nullable pair) add ga_prev*gw_extra[group]. */
+int64_t dd3d_arp_bwd_ws_bytes(int64_t M_in, int G);
+int dd3d_affine_relu_pool_bwd(const float* g_pool, const int32_t* arg, const int32_t* parent, const float* xhat, const float* w, const float* b,
+                              int use_affine_relu, int C, int64_t M_in, const int32_t* group_row_off, int G, float* g_xhat, float* ga_out,
+                              const float* ga_prev, const float* gw_extra, float* gw_w, float* gw_b, void* ws, int64_t ws_bytes, void* stream);
+int dd3d_scale_rows_by_group(const float* ga, const float* gw, const int32_t* group_row_off, int G, int64_t M, int C, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * (3b) classifier over the dense placement without the dense tensor
+ * replaces: SparseTensor.dense() + view(-1,100352) + nn.Linear(100352,10) and their autograd, models/MEConv.py:254-256
+ * strides[4] (HOST) = element strides of the weight-like operand over (group, output j, channel c, site s)
+ * ------------------------------------------------------------------------------------------------------------------- */
+int dd3d_sparse_linear_fwd(const float* F, const int32_t* site, const int32_t* seg_off, int B, int C, const int32_t* cloud_group, const float* Wl,
+                           const int64_t* strides, int J, const float* bias, float* out, void* stream);
+int dd3d_sparse_linear_bwd_x(const float* dl, const int32_t* site, const int32_t* seg_off, int B, int C, const int32_t* cloud_group, const float* Wl,
+                             const int64_t* strides, int J, int accumulate, float* dF, void* stream);
+int dd3d_sparse_linear_bwd_w(const float* dl, const float* F, const int32_t* vox_at, int S, const int32_t* group_cloud_off, int G, int C, int J,
+                             float* dWl, const int64_t* strides, int64_t dWl_elems, void* stream);
+
+/* mean softmax cross-entropy per group of clouds and its first / second-order backward.
+ * replaces: nn.CrossEntropyLoss + autograd, mnist_distill.py:302,344,355 */
+int dd3d_softmax_ce(const float* logits, const int32_t* labels, const int32_t* cloud_group, const int32_t* group_cloud_off, int G, int B, int J,
+                    float* prob, float* dlogits, float* cloud_loss, float* loss_g, void* stream);
+int dd3d_softmax_ce_bwd2(const float* prob, const float* u, const int32_t* group_cloud_off, int G, int J, int max_clouds_per_group, float* dz,
+                         void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * (4) gradient distance -- one segmented reduction over all layers, and its backward
+ * replaces: distance_wb / distance_mse / match_loss, distillation_loss.py:26-130
+ * ------------------------------------------------------------------------------------------------------------------- */
+#define DD3D_MAX_SEG 16
+#define DD3D_METRIC_OURS 0
+#define DD3D_METRIC_MODMSE 1
+#define DD3D_METRIC_MSE 2
+#define DD3D_METRIC_COS 3
+
+typedef struct dd3d_gseg {
+    const float* syn;  /* gradient of the synthetic batch, one layer */
+    const float* real; /* gradient of the real batch, same shape */
+    float* dsyn;       /* out (backward): d loss / d syn, or NULL */
+    int64_t rows;      /* logical rows after the reference's reshape (distillation_loss.py:27-47) */
+    int64_t cols;      /* logical columns */
+    int32_t colmajor;  /* 0: rows contiguous ([rows,cols] row-major).  1: element (r,q) at q*rows + r, i.e. a MinkowskiEngine kernel
+                          [K,Cin,Cout] viewed as permute(2,1,0) rows = Cout (distillation_loss.py:35-40) */
+    int32_t pad_;
+} dd3d_gseg;
+
+/* segs is a HOST array of n <= DD3D_MAX_SEG descriptors.  stats_dev needs dd3d_match_loss_stats_floats() floats and is kept for the
+ * backward.  loss_dev[1]. */
+int64_t dd3d_match_loss_ws_bytes(const dd3d_gseg* segs, int n);
+int64_t dd3d_match_loss_stats_floats(const dd3d_gseg* segs, int n);
+int dd3d_match_loss_fwd(const dd3d_gseg* segs, int n, int metric, float* loss_dev, float* stats_dev, void* ws, int64_t ws_bytes, void* stream);
+int dd3d_match_loss_bwd(const dd3d_gseg* segs, int n, int metric, const float* stats_dev, const float* gl_dev, void* ws, int64_t ws_bytes,
+                        void* stream);
+
+/* x -= lr * (mom = first_step ? grad : momentum*mom + grad); optional clamp to [lo,hi] with column 0 of every xyz row forced to 0.
+ * replaces: optimizer_img.step() and the next iteration's clamp, mnist_distill.py:369,311-317 */
+int dd3d_sgd_momentum_clamp(float* x, const float* grad, float* mom, int64_t n, float lr, float momentum, int first_step, int do_clamp, float lo,
+                            float hi, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DD3D_H */

@@ -172,6 +172,8 @@ def run_model_fixture(settings, Mnist2D, MEConv, dl, cls, pyt, fname, metrics):
     out = {}
     for metric in metrics:
         image_syn = init_synthetic(2, 2, num_points=250, seed=5)
+        image_syn[image_syn < 0] = 0      # the iteration prologue, mnist_distill.py:311-317
+        image_syn[image_syn > 27] = 27
         image_syn[:, :, 0] = 0
         image_syn.requires_grad_()
         rec = reference_step(settings, Mnist2D, MEConv, dl, net, image_syn, reals, 2, metric)

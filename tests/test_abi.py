@@ -1,0 +1,76 @@
+"""CPU-side checks of the C-ABI boundary: the library loads, exports every symbol include/dd3d.h declares, and the product path
+refuses to run without a GPU instead of falling back to anything."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "dd3d.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dd3d_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from dd3d_amd import _lib
+    syms = header_symbols()
+    assert len(syms) >= 30
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(raw, s), f"{s} declared in include/dd3d.h but not exported"
+    assert sorted(_lib.EXPORTS) == syms, "python binding table and header disagree"
+    assert _lib.lib.dd3d_version() >= 100
+
+
+def test_size_queries_are_pure_host_functions():
+    from dd3d_amd import _lib
+    cap = _lib.lib.dd3d_table_capacity(1000)
+    assert cap >= 2000 and cap & (cap - 1) == 0
+    assert _lib.lib.dd3d_unique_ws_bytes(1000, cap) > 0
+    assert _lib.lib.dd3d_conv_bwd_weight_ws_bytes(7000, 1, 27, 128, 128) > 0
+    seg = (_lib.GSeg * 1)()
+    assert _lib.lib.dd3d_match_loss_ws_bytes(seg, 1) == -1  # null pointers are an argument error, not a crash
+
+
+def test_gseg_struct_layout_matches_header():
+    from dd3d_amd import _lib
+    assert ctypes.sizeof(_lib.GSeg) == 48
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_no_cpu_fallback():
+    from dd3d_amd.sparse import CoordinateManager
+    with pytest.raises(RuntimeError):
+        CoordinateManager(torch.zeros(4, 4))
+    from dd3d_amd.distillation_loss import match_loss
+    with pytest.raises(RuntimeError):
+        match_loss([torch.zeros(3, requires_grad=True)], [torch.zeros(3)], "mse", "cpu")
+
+
+def test_model_constructors_match_reference_golden():
+    import numpy as np
+    from dd3d_amd.models.MEConv import MEConvExp, MEPytorch
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g5_ctor.npz"))
+    for name, net in (("MEConvExp", MEConvExp(in_channel=3, out_channel=10)), ("MEPytorch", MEPytorch(3, 10))):
+        assert [n for n, _ in net.named_parameters()] == list(g[name + ".names"])
+        assert [str(tuple(p.shape)) for p in net.parameters()] == list(g[name + ".shapes"])
+        assert list(net.state_dict().keys()) == list(g[name + ".sd_keys"])
+    net = MEConvExp(in_channel=3, out_channel=10)
+    std = [net.features[0].kernel.std().item(), net.features[4].kernel.std().item()]
+    assert std[0] == pytest.approx((2.0 / (128 * 27)) ** 0.5, rel=0.05) and std[1] == pytest.approx((2.0 / (128 * 27)) ** 0.5, rel=0.02)
+    assert float(net.features[1].weight.min()) == 1.0 and float(net.features[1].bias.abs().max()) == 0.0
+
+
+def test_loss_row_layout_follows_reference():
+    from dd3d_amd.distillation_loss import _rows_cols
+    assert _rows_cols((27, 3, 128), False) == (128, 81, 1)
+    assert _rows_cols((27, 3, 128), True) == (27, 384, 0)
+    assert _rows_cols((128, 3, 1, 3, 3), True) == (128, 27, 0)
+    assert _rows_cols((10, 100352), False) == (10, 100352, 0)
+    assert _rows_cols((1, 128), False) == (1, 128, 0)
+    assert _rows_cols((10,), False) == (1, 10, 0)

@@ -1,0 +1,323 @@
+"""GPU parity tests, op by op: every C-ABI entry point of libdd3d_hip.so against the CPU oracle (oracle/minkowski_ref.py) on the
+same seeded inputs.  Integer outputs (coordinates, maps, pair lists) must be bit-exact; fp32 outputs are compared with an fp64
+oracle at rel 2e-5 of the tensor's max magnitude."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import minkowski_ref as ME
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def make_coords(B, pts, extent, seed, dims3=False, neg=False):
+    rng = np.random.default_rng(seed)
+    rows = []
+    for b in range(B):
+        n = int(rng.integers(1, pts + 1))
+        c = rng.uniform(-extent if neg else 0, extent, size=(n, 3))
+        if not dims3:
+            c[:, 0] = 0
+        rows.append(np.concatenate([np.full((n, 1), b), c], 1))
+    return torch.tensor(np.concatenate(rows, 0), dtype=torch.float32)
+
+
+def manager(coords, B=None):
+    from dd3d_amd.sparse import CoordinateManager
+    return CoordinateManager(coords.to(dev()), B)
+
+
+CASES = [dict(B=5, pts=60, extent=12, seed=0), dict(B=3, pts=250, extent=28, seed=1),
+         dict(B=7, pts=100, extent=9, seed=2, dims3=True, neg=True), dict(B=1, pts=1, extent=3, seed=3),
+         dict(B=40, pts=300, extent=28, seed=4)]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_coordinate_maps_bit_exact(case):
+    coords = make_coords(**case)
+    cm = manager(coords)
+    C0, inv, uidx = ME.quantize_unique(coords)
+    M0 = cm.num_rows(1)
+    assert M0 == C0.shape[0]
+    assert torch.equal(cm.coordinates(1).cpu(), C0)
+    assert torch.equal(cm.levels[1].inv[:coords.shape[0]].cpu().long(), inv)
+    assert torch.equal(cm.levels[1].uidx[:M0].cpu().long(), uidx)
+    off, pts = ME.voxel_csr(inv, M0)
+    assert torch.equal(cm.vox_off[:M0 + 1].cpu().long(), off)
+    assert torch.equal(cm.vox_pts[:coords.shape[0]].cpu().long(), pts)
+    Cprev = C0
+    for ts in (2, 4):
+        Cs, parent = ME.stride_map(Cprev, ts)
+        assert cm.num_rows(ts) == Cs.shape[0]
+        assert torch.equal(cm.coordinates(ts).cpu(), Cs)
+        assert torch.equal(cm.parent(ts)[:Cprev.shape[0]].cpu().long(), parent)
+        Cprev = Cs
+    for (si, so, k) in ((1, 1, 3), (2, 2, 3), (1, 2, 2), (2, 4, 2)):
+        nbr, ld = cm.kernel_map(si, so, k)
+        Mo = cm.num_rows(so)
+        ref = ME.kernel_map(cm.coordinates(si).cpu(), cm.coordinates(so).cpu(), k, si)
+        assert torch.equal(nbr[:, :Mo].cpu().long(), ref)
+        ins, outs, offs = cm.pairs(si, so, k)
+        rins, routs, roffs = ME.pairs_from_nbr(ref)
+        assert torch.equal(offs.cpu().long(), roffs)
+        assert torch.equal(ins.cpu().long(), rins) and torch.equal(outs.cpu().long(), routs)
+    B = case["B"]
+    seg = cm.seg_off(1).cpu().long()
+    b = C0[:, 0].long()
+    assert torch.equal(seg, torch.searchsorted(b, torch.arange(B + 1)))
+    cm.sync()
+
+
+def test_lazy_pyramid_single_sync_matches_eager():
+    coords = make_coords(B=6, pts=120, extent=20, seed=9)
+    cm = manager(coords, 6)
+    k0 = cm.kernel_map(1, 1, 3)
+    p0 = cm.kernel_map(1, 2, 2)
+    k1 = cm.kernel_map(2, 2, 3)
+    p1 = cm.kernel_map(2, 4, 2)
+    assert all(lv.M is None for lv in cm.levels.values())  # nothing read back yet
+    cm.sync()
+    cm2 = manager(coords, 6)
+    for ts in (1, 2, 4):
+        cm2.num_rows(ts)  # eager: sync at every level
+        assert torch.equal(cm.coordinates(ts), cm2.coordinates(ts))
+    for (key, (nbr, ld)) in (((1, 1, 3), k0), ((1, 2, 2), p0), ((2, 2, 3), k1), ((2, 4, 2), p1)):
+        n2, _ = cm2.kernel_map(*key)
+        Mo = cm.num_rows(key[1])
+        assert torch.equal(nbr[:, :Mo], n2[:, :Mo])
+
+
+def test_empty_and_duplicate_inputs():
+    cm = manager(torch.zeros((0, 4)), 0)
+    assert cm.num_rows(1) == 0 and cm.num_rows(2) == 0
+    c = torch.tensor([[0, 0, 3.5, 4.5]] * 70 + [[1, 0, 3.5, 4.5]] * 3)
+    cm = manager(c)
+    assert cm.num_rows(1) == 2
+    assert cm.levels[1].inv[:73].cpu().tolist() == [0] * 70 + [1] * 3
+    assert cm.vox_pts[:73].cpu().tolist() == list(range(73))
+
+
+def test_unsorted_batch_index_is_reported():
+    c = torch.tensor([[1, 0, 1.0, 1.0], [0, 0, 2.0, 2.0]])
+    cm = manager(c, 2)
+    cm.seg_off(1)
+    with pytest.raises(RuntimeError):
+        cm.sync()
+
+
+@pytest.mark.parametrize("case", CASES[:3])
+def test_voxel_mean(case):
+    from dd3d_amd.ops import voxel_mean
+    coords = make_coords(**case)
+    g = torch.Generator().manual_seed(5)
+    feats = torch.randn(coords.shape[0], 3, generator=g)
+    cm = manager(coords)
+    f = feats.to(dev()).requires_grad_()
+    F0 = voxel_mean(f, cm)
+    _, inv, _ = ME.quantize_unique(coords)
+    fr = feats.double().requires_grad_()
+    R0 = ME.VoxelMeanFn.apply(fr, inv, cm.num_rows(1))
+    assert rel_err(F0, R0) < 1e-6
+    w = torch.randn(R0.shape, generator=g, dtype=torch.float64)
+    (R0 * w).sum().backward()
+    (F0 * w.float().to(dev())).sum().backward()
+    assert rel_err(f.grad, fr.grad) < 1e-6
+
+
+def _conv_case(case, Cin, seed=0, stride=1):
+    coords = make_coords(**case)
+    cm = manager(coords)
+    M = cm.num_rows(stride)
+    nbr, ld = cm.kernel_map(stride, stride, 3)
+    g = torch.Generator().manual_seed(seed)
+    X = torch.randn(M, Cin, generator=g)
+    W = torch.randn(27, Cin, 128, generator=g) * 0.1
+    return cm, M, nbr, ld, X, W
+
+
+@pytest.mark.parametrize("case", CASES[:3] + [CASES[4]])
+@pytest.mark.parametrize("Cin", [3, 128])
+def test_conv_forward_backward(case, Cin):
+    from dd3d_amd.ops import SparseConvFn
+    cm, M, nbr, ld, X, W = _conv_case(case, Cin)
+    x = X.to(dev()).requires_grad_()
+    w = W.to(dev()).requires_grad_()
+    Y = SparseConvFn.apply(x, w, nbr, ld, M)
+    ref_nbr = ME.kernel_map(cm.coordinates(1).cpu(), cm.coordinates(1).cpu(), 3, 1)
+    xr, wr = X.double().requires_grad_(), W.double().requires_grad_()
+    Yr = ME.SparseConvFn.apply(xr, wr, ref_nbr)
+    assert rel_err(Y, Yr) < 2e-5
+    gy = torch.randn(Yr.shape, generator=torch.Generator().manual_seed(3), dtype=torch.float64)
+    (Yr * gy).sum().backward()
+    (Y * gy.float().to(dev())).sum().backward()
+    assert rel_err(x.grad, xr.grad) < 2e-5
+    assert rel_err(w.grad, wr.grad) < 2e-5
+
+
+def test_conv_bwd_weight_grouped_and_deterministic():
+    from dd3d_amd.ops import conv_bwd_weight
+    cm, M, nbr, ld, X, W = _conv_case(dict(B=40, pts=300, extent=28, seed=4), 128)
+    seg = cm.seg_off(1)
+    gco = [0, 7, 7, 25, 40]  # 4 groups of clouds, one of them empty
+    gro = seg[torch.tensor(gco, device=dev())].contiguous()
+    dY = torch.randn(M, 128, generator=torch.Generator().manual_seed(8))
+    x, dy = X.to(dev()), dY.to(dev())
+    dW = conv_bwd_weight(x, dy, nbr, ld, M, gro, 4)
+    dW2 = conv_bwd_weight(x, dy, nbr, ld, M, gro, 4)
+    assert torch.equal(dW, dW2)  # bitwise reproducible
+    ref_nbr = ME.kernel_map(cm.coordinates(1).cpu(), cm.coordinates(1).cpu(), 3, 1)
+    rows = gro.cpu().tolist()
+    for gi in range(4):
+        a, b = rows[gi], rows[gi + 1]
+        ref = torch.zeros(27, 128, 128, dtype=torch.float64)
+        for k in range(27):
+            o = torch.nonzero(ref_nbr[k, a:b] >= 0).reshape(-1) + a
+            if o.numel():
+                ref[k] = X.double()[ref_nbr[k][o]].t() @ dY.double()[o]
+        if a == b:
+            assert float(dW[gi].abs().max()) == 0.0
+        else:
+            assert rel_err(dW[gi], ref) < 2e-5
+
+
+@pytest.mark.parametrize("case", CASES[:3])
+def test_instance_norm(case):
+    from dd3d_amd.ops import InstanceNormFn
+    coords = make_coords(**case)
+    cm = manager(coords)
+    M, B = cm.num_rows(1), cm.B
+    g = torch.Generator().manual_seed(1)
+    X = torch.randn(M, 128, generator=g) * 3 + 1
+    x = X.to(dev()).requires_grad_()
+    out = InstanceNormFn.apply(x, cm.seg_off(1), B)
+    xr = X.double().requires_grad_()
+    b = cm.coordinates(1)[:, 0].cpu().long()
+    ref = ME.InstanceNormFn.apply(xr, b, B)
+    assert rel_err(out, ref) < 2e-5
+    gy = torch.randn(M, 128, generator=g, dtype=torch.float64)
+    (ref * gy).sum().backward()
+    (out * gy.float().to(dev())).sum().backward()
+    assert rel_err(x.grad, xr.grad) < 5e-5
+
+
+def test_instance_norm_single_voxel_and_empty_cloud():
+    from dd3d_amd.ops import InstanceNormFn
+    coords = torch.tensor([[0, 0, 1.0, 1.0], [2, 0, 1.0, 1.0], [2, 0, 5.0, 1.0]])  # cloud 1 is empty
+    cm = manager(coords, 3)
+    X = torch.tensor([[3.0] * 128, [1.0] * 128, [2.0] * 128])
+    out = InstanceNormFn.apply(X.to(dev()), cm.seg_off(1), 3).cpu()
+    assert float(out[0].abs().max()) == 0.0
+    np.testing.assert_allclose(out[1:].numpy(), np.array([[-1.0] * 128, [1.0] * 128]), rtol=1e-5)
+
+
+@pytest.mark.parametrize("case", CASES[:3])
+def test_max_pool(case):
+    from dd3d_amd.ops import MaxPoolFn
+    coords = make_coords(**case)
+    cm = manager(coords)
+    M, Mo = cm.num_rows(1), cm.num_rows(2)
+    kids, ld = cm.kernel_map(1, 2, 2)
+    g = torch.Generator().manual_seed(2)
+    X = torch.randn(M, 128, generator=g) - 2.0  # mostly negative: absent children must not act as zeros
+    x = X.to(dev()).requires_grad_()
+    out = MaxPoolFn.apply(x, kids, ld, cm.parent(2), Mo)
+    rk = ME.kernel_map(cm.coordinates(1).cpu(), cm.coordinates(2).cpu(), 2, 1)
+    xr = X.double().requires_grad_()
+    ref, _ = ME.MaxPoolFn.apply(xr, rk)
+    assert torch.equal(out.cpu().double(), ref.detach())
+    gy = torch.randn(Mo, 128, generator=g, dtype=torch.float64)
+    (ref * gy).sum().backward()
+    (out * gy.float().to(dev())).sum().backward()
+    assert torch.equal(x.grad.cpu().double(), xr.grad.float().double())
+
+
+def _block_oracle(Y, w, b, bidx, B, kids):
+    xh = ME.InstanceNormFn.apply(Y, bidx, B)
+    a = torch.relu(xh * w + b)
+    out, _ = ME.MaxPoolFn.apply(a, kids)
+    return out
+
+
+@pytest.mark.parametrize("case", CASES[:3])
+def test_fused_norm_act_pool_first_and_second_order(case):
+    """NormActPoolFn against the op-by-op oracle, including the create_graph path: d/dY of <gw_weight, t>."""
+    from dd3d_amd.ops import NormActPoolFn, _single_group
+    coords = make_coords(**case)
+    cm = manager(coords)
+    M, Mo, B = cm.num_rows(1), cm.num_rows(2), cm.B
+    kids, ld = cm.kernel_map(1, 2, 2)
+    g = torch.Generator().manual_seed(4)
+    Y0 = torch.randn(M, 128, generator=g) * 2
+    w0 = 1 + 0.2 * torch.randn(1, 128, generator=g)
+    b0 = 0.2 * torch.randn(1, 128, generator=g)
+    gp = torch.randn(Mo, 128, generator=g, dtype=torch.float64)
+    t = torch.randn(1, 128, generator=g, dtype=torch.float64)
+    y, w, b = (v.to(dev()).requires_grad_() for v in (Y0, w0, b0))
+    out = NormActPoolFn.apply(y, w, b, cm.seg_off(1), B, kids, ld, cm.parent(2), Mo, _single_group(M, dev()), 1)
+    yr, wr, br = (v.double().requires_grad_() for v in (Y0, w0, b0))
+    bidx = cm.coordinates(1)[:, 0].cpu().long()
+    rk = ME.kernel_map(cm.coordinates(1).cpu(), cm.coordinates(2).cpu(), 2, 1)
+    ref = _block_oracle(yr, wr, br, bidx, B, rk)
+    assert rel_err(out, ref) < 2e-5
+    gy, gw, gb = torch.autograd.grad((out * gp.float().to(dev())).sum(), [y, w, b], create_graph=True)
+    ry, rw, rb = torch.autograd.grad((ref * gp).sum(), [yr, wr, br], create_graph=True)
+    assert rel_err(gy, ry) < 5e-5 and rel_err(gw, rw) < 5e-5 and rel_err(gb, rb) < 5e-5
+    assert not ry.requires_grad and not rb.requires_grad  # oracle: constants, as in MinkowskiEngine
+    (g2,) = torch.autograd.grad((gw * t.float().to(dev())).sum(), [y])
+    (r2,) = torch.autograd.grad((rw * t).sum(), [yr])
+    assert rel_err(g2, r2) < 5e-5
+
+
+def test_sparse_linear_closed_under_differentiation():
+    from dd3d_amd.ops import DensePlacement, sparse_linear
+    coords = make_coords(B=6, pts=200, extent=28, seed=6)
+    cm = manager(coords)
+    ts = 4
+    M2, B = cm.num_rows(ts), cm.B
+    dp = DensePlacement(cm, ts, (1, 28, 28))
+    cm.sync()
+    g = torch.Generator().manual_seed(7)
+    F0 = torch.randn(M2, 128, generator=g)
+    W0 = torch.randn(10, 100352, generator=g) * 0.05
+    b0 = torch.randn(10, generator=g)
+    u = torch.randn(B, 10, generator=g, dtype=torch.float64)
+    f, w, b = (v.to(dev()).requires_grad_() for v in (F0, W0, b0))
+    out = sparse_linear(f, w, b, dp)
+    st = ME.SparseTensor(F0.double().requires_grad_(), cm.coordinates(ts).cpu(), ts)
+    fr = st.F
+    wr, br = W0.double().requires_grad_(), b0.double().requires_grad_()
+    minc = st.C.min(0, keepdim=True)[0][:, 1:]
+    dense = st.dense(shape=torch.Size([B, 128, 1, 28, 28]), min_coordinate=minc)[0]
+    ref = dense.view(B, -1) @ wr.t() + br
+    assert rel_err(out, ref) < 2e-5
+    # first order, kept differentiable
+    L1 = (torch.tanh(out) * u.float().to(dev())).sum()
+    R1 = (torch.tanh(ref) * u).sum()
+    gf, gw, gb = torch.autograd.grad(L1, [f, w, b], create_graph=True)
+    rf, rw, rb = torch.autograd.grad(R1, [fr, wr, br], create_graph=True)
+    assert rel_err(gf, rf) < 2e-5 and rel_err(gw, rw) < 2e-5 and rel_err(gb, rb) < 2e-5
+    # second order through dW (the matching-loss path) and through dF
+    L2 = (gw ** 2).sum() + (gf * gf).sum() + (gb ** 2).sum()
+    R2 = (rw ** 2).sum() + (rf * rf).sum() + (rb ** 2).sum()
+    hf, hw = torch.autograd.grad(L2, [f, w])
+    qf, qw = torch.autograd.grad(R2, [fr, wr])
+    assert rel_err(hf, qf) < 5e-5 and rel_err(hw, qw) < 5e-5
+
+
+def test_dense_out_of_extent_is_an_error():
+    from dd3d_amd.ops import DensePlacement
+    coords = torch.tensor([[0, 0, 0.0, 0.0], [0, 0, 0.0, 200.0]])
+    cm = manager(coords, 1)
+    DensePlacement(cm, 4, (1, 28, 28))
+    with pytest.raises(IndexError):
+        cm.sync()

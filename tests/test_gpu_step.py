@@ -1,0 +1,168 @@
+"""GPU parity tests of the whole hot path: match_loss, MEConvExp / MEPytorch forward + gradients, and one full matching step,
+against (a) the golden vectors produced by the reference's own files and (b) the CPU oracle on seeded inputs.
+Tolerance: rel 1e-4 on losses and coordinate gradients (BASELINE.json north_star), fp32."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_model as R
+from dd3d_amd.synthetic import init_synthetic, stroke_digits
+from tests.detgen import det_state_dict, det_tensor, sample_idx
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+EXP_SHAPES = [(27, 3, 128), (1, 128), (1, 128), (27, 128, 128), (1, 128), (1, 128), (10, 100352), (10,)]
+PYT_SHAPES = [(128, 3, 1, 3, 3), (128,), (128, 128, 1, 3, 3), (128,), (128, 128, 1, 3, 3), (128,), (10, 1152), (10,)]
+DEV = "cuda:0"
+
+
+def rel_err(a, b):
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize("fam,shapes", [("exp", EXP_SHAPES), ("pyt", PYT_SHAPES)])
+@pytest.mark.parametrize("pyt", [False, True])
+@pytest.mark.parametrize("metric", ["ours", "modmse", "mse", "cos"])
+def test_match_loss_vs_reference_golden(fam, shapes, pyt, metric):
+    from dd3d_amd.configs import settings
+    from dd3d_amd.distillation_loss import match_loss
+    g = np.load(os.path.join(G, "g1_match_loss.npz"))
+    real = [det_tensor(s, f"g1.{fam}.real.{i}", 0.05).to(DEV) for i, s in enumerate(shapes)]
+    syn = [det_tensor(s, f"g1.{fam}.syn.{i}", 0.05).to(DEV).requires_grad_() for i, s in enumerate(shapes)]
+    settings.Pyt = pyt
+    try:
+        v = match_loss(syn, real, metric, DEV)
+        grads = torch.autograd.grad(v * 1.0, syn)
+    finally:
+        settings.Pyt = False
+    key = f"{fam}.{int(pyt)}.{metric}"
+    assert v.item() == pytest.approx(float(g[key + ".value"]), rel=1e-5)
+    for i, gr in enumerate(grads):
+        assert gr.shape == syn[i].shape
+        assert gr.double().norm().item() == pytest.approx(g[key + ".gnorm"][i], rel=1e-4, abs=1e-10)
+        idx = sample_idx(gr.numel(), f"{fam}.{i}")
+        np.testing.assert_allclose(gr.reshape(-1)[idx].cpu().numpy(), g[key + ".gsample"][i][:len(idx)], rtol=1e-4, atol=1e-8)
+
+
+def test_match_loss_unknown_metric_exits():
+    from dd3d_amd.distillation_loss import match_loss
+    with pytest.raises(SystemExit):
+        match_loss([torch.zeros(3, device=DEV)], [torch.zeros(3, device=DEV)], "nope", DEV)
+
+
+def test_match_loss_upstream_gradient_scales():
+    from dd3d_amd.distillation_loss import match_loss
+    real = [det_tensor(s, f"ug.real.{i}", 0.05).to(DEV) for i, s in enumerate(EXP_SHAPES)]
+    syn = [det_tensor(s, f"ug.syn.{i}", 0.05).to(DEV).requires_grad_() for i, s in enumerate(EXP_SHAPES)]
+    g1 = torch.autograd.grad(match_loss(syn, real, "ours", DEV), syn)
+    g3 = torch.autograd.grad(3.0 * match_loss(syn, real, "ours", DEV), syn)
+    for a, b in zip(g1, g3):
+        assert rel_err(b, 3.0 * a) < 1e-6
+
+
+def _load(net_cls, oracle_cls, pyt):
+    torch.manual_seed(0)
+    net = net_cls(3, 10) if pyt else net_cls(in_channel=3, out_channel=10)
+    sd = det_state_dict(net, "net." + oracle_cls.__name__)
+    net.load_state_dict(sd)
+    return net.to(DEV).train()
+
+
+def _distiller(net, reals, ipc, metric, nclass):
+    from dd3d_amd.mnist_distill import Distiller
+    from dd3d_amd.utils.Mnist2D import batch_from_images
+    image_syn = init_synthetic(nclass, ipc, num_points=250, seed=5)
+    images_all = torch.cat(reals, 0)
+    per = reals[0].shape[0]
+    d = Distiller(images_all, [list(range(c * per, (c + 1) * per)) for c in range(nclass)], net, ipc=ipc, num_classes=nclass,
+                  batch_size=per, dist_opt=metric, device=DEV, image_syn=image_syn)
+    batches = [batch_from_images(r.to(DEV), torch.full((per,), c, device=DEV), 250) for c, r in enumerate(reals)]
+    return d, batches
+
+
+@pytest.mark.parametrize("metric", ["modmse", "ours"])
+@pytest.mark.parametrize("fused", [True, False])
+def test_meconvexp_step_vs_reference_golden(metric, fused):
+    """One matching step of MEConvExp: reference topology code (run over the ME restatement) vs the HIP path."""
+    from dd3d_amd.models.MEConv import MEConvExp
+    g = np.load(os.path.join(G, "g4_meconvexp.npz"))
+    net = _load(MEConvExp, R.MEConvExp, False)
+    net.fused = fused
+    reals = [stroke_digits(4, seed=100 + c) for c in range(2)]
+    d, batches = _distiller(net, reals, 2, metric, 2)
+    loss = d.outer_step(real_batches=batches, apply_update=False)
+    assert loss.item() == pytest.approx(float(g[metric + ".loss"]), rel=1e-4)
+    np.testing.assert_allclose(torch.stack(d.last["per_class"]).cpu().numpy(), g[metric + ".per_class"], rtol=1e-4)
+    assert rel_err(d.last["grad"], g[metric + ".grad"]) < 1e-4
+    for c in range(2):
+        assert rel_err(d.last["logits"][c][0], g[metric + ".logits_real"][c]) < 1e-4
+        assert rel_err(d.last["logits"][c][1], g[metric + ".logits_syn"][c]) < 1e-4
+        np.testing.assert_allclose([t.double().norm().item() for t in d.last["gw_real"][c]], g[metric + ".gwr_norm"][c], rtol=1e-4)
+        np.testing.assert_allclose([t.double().norm().item() for t in d.last["gw_syn"][c]], g[metric + ".gws_norm"][c], rtol=1e-4)
+
+
+@pytest.mark.parametrize("metric", ["modmse", "ours"])
+def test_mepytorch_step_vs_reference_golden(metric):
+    from dd3d_amd.configs import settings
+    from dd3d_amd.models.MEConv import MEPytorch
+    g = np.load(os.path.join(G, "g3_mepytorch.npz"))
+    net = _load(MEPytorch, R.MEPytorch, True)
+    reals = [stroke_digits(4, seed=100 + c) for c in range(2)]
+    d, batches = _distiller(net, reals, 2, metric, 2)
+    settings.Pyt = True
+    try:
+        loss = d.outer_step(real_batches=batches, apply_update=False)
+    finally:
+        settings.Pyt = False
+    assert loss.item() == pytest.approx(float(g[metric + ".loss"]), rel=2e-4)
+    assert rel_err(d.last["grad"], g[metric + ".grad"]) < 2e-4
+    for c in range(2):
+        assert rel_err(d.last["logits"][c][0], g[metric + ".logits_real"][c]) < 1e-4
+
+
+@pytest.mark.parametrize("metric", ["modmse", "ours", "cos"])
+def test_meconvexp_step_vs_oracle_midsize(metric):
+    """3 classes x 24 real clouds, ipc 3, fp64 oracle on the CPU vs the HIP path; then the SGD update itself."""
+    from dd3d_amd.models.MEConv import MEConvExp
+    net = _load(MEConvExp, R.MEConvExp, False)
+    onet = R.MEConvExp(in_channel=3, out_channel=10)
+    onet.load_state_dict(det_state_dict(onet, "net.MEConvExp"))
+    onet = onet.double().train()
+    reals = [stroke_digits(24, seed=200 + c) for c in range(3)]
+    d, batches = _distiller(net, reals, 3, metric, 3)
+    osyn = d.image_syn.detach().cpu().double().clone()
+    R.clamp_synthetic_(osyn)
+    osyn.requires_grad_()
+    opt = torch.optim.SGD([osyn], lr=0.1, momentum=0.5)
+    ref = R.matching_step(onet, osyn, reals, 3, metric, False, optimizer=opt)
+    loss = d.outer_step(real_batches=batches, apply_update=True)
+    assert loss.item() == pytest.approx(ref["loss"].item(), rel=1e-4)
+    assert rel_err(d.last["grad"], ref["grad"]) < 1e-4
+    assert rel_err(d.image_syn, osyn) < 1e-5
+    for c in range(3):
+        for a, b in zip(d.last["gw_real"][c], ref["gw_real"][c]):
+            assert rel_err(a, b) < 1e-4
+        for a, b in zip(d.last["gw_syn"][c], ref["gw_syn"][c]):
+            assert rel_err(a, b) < 1e-4
+
+
+def test_batch_from_images_equals_per_item_collate():
+    from dd3d_amd.utils.Mnist2D import Mnist2Dreal, batch_from_images, get_mnist_dataloader
+    g = np.load(os.path.join(G, "g2_plumbing.npz"))
+    imgs = stroke_digits(4, seed=11)
+    imgs[3] = 0
+    imgs[3, 0, 5, 7] = 1
+    labels = torch.tensor([3, 1, 4, 1])
+    b = batch_from_images(imgs.to(DEV), labels.to(DEV), 250)
+    np.testing.assert_array_equal(b["coordinates"].cpu().numpy(), g["real.coordinates"])
+    np.testing.assert_array_equal(b["features"].cpu().numpy(), g["real.features"])
+    np.testing.assert_array_equal(b["labels"].cpu().numpy(), g["real.labels"])
+    b20 = batch_from_images(imgs.to(DEV), labels.to(DEV), 20)
+    np.testing.assert_array_equal(b20["coordinates"].cpu().numpy(), g["real20.coordinates"])
+    (pb,) = list(get_mnist_dataloader(Mnist2Dreal(imgs, labels, False), 4))
+    np.testing.assert_array_equal(pb["coordinates"].numpy(), g["real.coordinates"])

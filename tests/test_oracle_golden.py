@@ -66,7 +66,7 @@ def _run_step(cls, pyt, metric, dtype=torch.float32):
     net = net.to(dtype).train()
     reals = [stroke_digits(4, seed=100 + c) for c in range(2)]
     image_syn = init_synthetic(2, 2, num_points=250, seed=5)
-    image_syn[:, :, 0] = 0
+    R.clamp_synthetic_(image_syn)
     image_syn = image_syn.to(dtype).requires_grad_()
     return R.matching_step(net, image_syn, reals, 2, metric, pyt)
 
