@@ -58,26 +58,33 @@ def voxel_mean(feats, cm):
 
 
 # ----------------------------------------------------------------------------------------------- convolution
-_wt_cache = {}
-
-
 def transposed_kernel(W: torch.Tensor) -> torch.Tensor:
-    """Wt[k][co][ci] for the backward-data pass, cached per (storage, version)."""
-    key = (W.data_ptr(), W._version, tuple(W.shape))
-    hit = _wt_cache.get(W.data_ptr())
-    if hit is not None and hit[0] == key:
+    """Wt[k][co][ci] for the backward-data pass; cached ON the weight tensor and invalidated by its version counter."""
+    hit = getattr(W, "_dd3d_wt", None)
+    if hit is not None and hit[0] == W._version and hit[1].device == W.device:
         return hit[1]
     K, Cin, Cout = W.shape
     Wt = torch.empty((K, Cout, Cin), dtype=_F32, device=W.device)
     L.call("dd3d_transpose_kernel", L.ptr(_c(W)), K, Cin, Cout, L.ptr(Wt), L.stream())
-    if len(_wt_cache) > 64:
-        _wt_cache.clear()
-    _wt_cache[W.data_ptr()] = (key, Wt)
+    try:
+        W._dd3d_wt = (W._version, Wt)
+    except Exception:
+        pass
     return Wt
 
 
+_group_cache = {}
+
+
 def _single_group(M: int, device) -> torch.Tensor:
-    return torch.tensor([0, M], dtype=torch.int32, device=device)
+    """group_row_off of a single group [0, M) (cached: building a device tensor from host values is a blocking copy)."""
+    key = (int(M), str(device))
+    t = _group_cache.get(key)
+    if t is None:
+        if len(_group_cache) > 4096:
+            _group_cache.clear()
+        t = _group_cache[key] = torch.tensor([0, M], dtype=torch.int32, device=device)
+    return t
 
 
 def conv_bwd_weight(X, dY, nbr, ld, M_out, group_row_off, G):
