@@ -1,0 +1,171 @@
+"""Benchmark of the gradient-matching outer step (BASELINE.json metric) on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One step = mnist_distill.py:309-374 without evaluation / logging / export: all classes, real + synthetic forward/backward,
+match_loss, backward into the synthetic xyz, SGD update.  Workload = BASELINE.json configs[1] (cfg2 of SURVEY.md section 8d):
+MNIST-3D-shaped synthetic stroke digits, 10 classes x 256 real clouds, 10 synthetic clouds/class x 250 points, MEConvExp, modmse.
+Classes are sharded over the ranks (class c -> rank c mod N, fixed total work => "strong" scaling); the only collective is the
+all-reduce of the scalar matching loss.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NUM_CLASSES, REAL_PER_CLASS, IPC, NUM_POINTS, POOL_PER_CLASS = 10, 256, 10, 250, 512
+METRIC = "gradient-matching outer steps/sec (MNIST-3D, 10 cls)"
+
+
+class KernelTimer:
+    """HIP-event timing of one C-ABI entry point on the stream it is launched on (torch's current stream)."""
+
+    def __init__(self, name, pred):
+        self.name, self.pred, self.records, self.on = name, pred, [], False
+
+    def install(self):
+        from dd3d_amd import _lib as L
+        orig = L.call
+        timer = self
+
+        def call(name, *args):
+            if timer.on and name == timer.name and timer.pred(args):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                orig(name, *args)
+                e1.record()
+                timer.records.append((e0, e1, args))
+            else:
+                orig(name, *args)
+
+        L.call = call  # every module calls through dd3d_amd._lib.call
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--ipc", type=int, default=IPC)
+    ap.add_argument("--metric-name", default="modmse", help="dist_opt: modmse (INI default) | ours | mse | cos")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from dd3d_amd.mnist_distill import Distiller
+    from dd3d_amd.models.MEConv import MEConvExp
+    from dd3d_amd.synthetic import init_synthetic, mnist3d_like
+    from dd3d_amd import ops as _ops
+
+    torch.manual_seed(0)
+    images_all, _labels, indices_class = mnist3d_like(NUM_CLASSES, POOL_PER_CLASS, seed=0)
+    net = MEConvExp(in_channel=3, out_channel=10)
+    syn = init_synthetic(NUM_CLASSES, args.ipc, NUM_POINTS, seed=0)
+    my_classes = [c for c in range(NUM_CLASSES) if c % world == rank]
+    d = Distiller(images_all, indices_class, net, ipc=args.ipc, num_classes=NUM_CLASSES, num_points=NUM_POINTS, batch_size=REAL_PER_CLASS,
+                  dist_opt=args.metric_name, device=dev, seed=1234, image_syn=syn, classes=my_classes)
+
+    # ---- live timing of the dominant kernel: the Cin=128 sparse convolution forward (fp32 MFMA) ----
+    timer = KernelTimer("dd3d_conv_fwd", lambda a: a[2] == 128 and a[9] == 0)
+    nbr_keep = []
+    orig_apply_fwd = _ops.SparseConvFn.forward
+
+    def fwd_keep(ctx, X, W, nbr, ld, M_out):
+        if timer.on and W.shape[1] == 128:
+            nbr_keep.append((nbr, M_out))
+        return orig_apply_fwd(ctx, X, W, nbr, ld, M_out)
+
+    _ops.SparseConvFn.forward = staticmethod(fwd_keep)
+    timer.install()
+
+    def sync_all():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def one_step():
+        loss = d.outer_step()
+        if world > 1:
+            torch.distributed.all_reduce(loss)  # summed matching loss (mnist_distill.py:361,373), 4 bytes over RCCL
+        return loss
+
+    for _ in range(args.warmup):
+        one_step()
+    sync_all()
+    timer.on = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    timer.on = False
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms = [e0.elapsed_time(e1) for (e0, e1, _a) in timer.records]
+        pairs = [int((nbr[:, :M] >= 0).sum().item()) for (nbr, M) in nbr_keep]
+        flops = [2.0 * p * 128 * 128 for p in pairs]
+        avg_ms = sum(ms) / max(len(ms), 1)
+        avg_flop = sum(flops) / max(len(flops), 1)
+        roof = {"bound": "mfma", "kernel": "k_conv128 (dd3d_conv_fwd, Cin=Cout=128, fp32 MFMA 32x32x2)", "achieved": avg_flop / (avg_ms * 1e-3) / 1e12,
+                "peak": 157.3, "unit": "TFLOP/s", "traffic": None, "launches": len(ms), "avg_launch_us": avg_ms * 1e3,
+                "avg_pairs_per_launch": sum(pairs) / max(len(pairs), 1)}
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        out = {"metric": METRIC, "value": args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+               "data": "synthetic", "config": {"workload": f"cfg2: MNIST-3D-shaped stroke digits, {NUM_CLASSES} classes x {REAL_PER_CLASS} real clouds, "
+                                                           f"ipc={args.ipc} x {NUM_POINTS} pts, MEConvExp, dist_opt={args.metric_name}",
+                                               "parallelism": f"class-sharded x{world}", "path": "drop-in autograd loop"},
+               "loss": float(loss.item()), "roofline": roof}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(images_all, indices_class, net, syn, args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def cpu_baseline(images_all, indices_class, net, syn, args):
+    """The CPU oracle (torch restatement of the reference + MinkowskiEngine semantics) on the host cores, on a bounded sample of the
+    same workload: the first 2 of the 10 classes (classes are independent and equally sized), scaled to a full step."""
+    from oracle import ref_model as R
+    import numpy as np
+    sample_classes = 2
+    onet = R.MEConvExp(in_channel=3, out_channel=10)
+    onet.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()})
+    rng = np.random.RandomState(1234)
+    reals = [images_all[rng.permutation(indices_class[c])[:REAL_PER_CLASS]] for c in range(sample_classes)]
+    osyn = syn[: sample_classes * args.ipc].clone()
+    R.clamp_synthetic_(osyn)
+    osyn.requires_grad_()
+    opt = torch.optim.SGD([osyn], lr=0.1, momentum=0.5)
+    t0 = time.perf_counter()
+    R.matching_step(onet, osyn, reals, args.ipc, args.metric_name, False, optimizer=opt)
+    t = time.perf_counter() - t0
+    return {"value": 1.0 / (t * NUM_CLASSES / sample_classes), "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{sample_classes} of {NUM_CLASSES} classes of the same workload, one step, {t:.1f} s of CPU work, scaled x{NUM_CLASSES // sample_classes}"}
+
+
+if __name__ == "__main__":
+    main()

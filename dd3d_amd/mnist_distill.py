@@ -21,7 +21,7 @@ from .utils.Mnist2D import Mnist2Dsyn, batch_from_images, get_mnist_dataloader
 
 class Distiller:
     def __init__(self, images_all, indices_class, network, ipc, num_classes=10, num_points=250, batch_size=256, dist_opt="modmse",
-                 dist_lr=0.1, device=None, seed=0, image_syn=None):
+                 dist_lr=0.1, device=None, seed=0, image_syn=None, classes=None):
         self.device = torch.device(device or settings.device)
         self.images_all = images_all.to(self.device)
         self.indices_class = [np.asarray(ix) for ix in indices_class]
@@ -29,6 +29,8 @@ class Distiller:
         self.net_parameters = list(self.network.parameters())
         self.num_classes, self.ipc, self.num_points, self.batch_size = num_classes, ipc, num_points, batch_size
         self.dist_opt, self.rng = dist_opt, np.random.RandomState(seed)
+        # classes owned by this process (class sharding): every class is independent inside a step
+        self.classes = list(range(num_classes)) if classes is None else list(classes)
         settings.num_points, settings.cad_per_class = num_points, ipc
         if image_syn is None:  # :295-299
             g = torch.Generator().manual_seed(seed)
@@ -82,15 +84,16 @@ class Distiller:
         self.clamp()
         self.last = {"per_class": [], "gw_real": [], "gw_syn": []}
         loss = torch.zeros((), device=self.device)
-        for c in range(self.num_classes):
+        for c in self.classes:
             m, gwr, gws = self.class_loss(c, None if real_batches is None else real_batches[c])
             loss = loss + m
             self.last["per_class"].append(m.detach())
             self.last["gw_real"].append(gwr)
             self.last["gw_syn"].append([g.detach() for g in gws])
         self.optimizer_img.zero_grad()
-        loss.backward()
-        self.last["grad"] = self.image_syn.grad.detach().clone()
+        if loss.requires_grad:
+            loss.backward()
+        self.last["grad"] = self.image_syn.grad.detach().clone() if self.image_syn.grad is not None else None
         if apply_update:
             self.optimizer_img.step()
         return loss.detach()
