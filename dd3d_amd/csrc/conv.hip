@@ -284,33 +284,75 @@ __global__ __launch_bounds__(256) void k_conv3_bwd_data(const float* __restrict_
     }
 }
 
-// dW[g][k][ci][co] partial per row chunk: thread = output channel, 81 accumulators in registers (fully unrolled over k)
-__global__ __launch_bounds__(128) void k_conv3_bww(const float* __restrict__ X, const float* __restrict__ dY, const int* __restrict__ nbr, int64_t ld,
+// dW[g][k][ci][co] partial per row chunk on the fp32 matrix cores: out[81 (pad 96)][128] = A^T . dY with the im2col tile
+// A[o][k*3+ci] = X[nbr[k][o]][ci] built in LDS (32 rows at a time).  Wave w owns output columns [32w, 32w+32) and all 3 row tiles.
+__global__ __launch_bounds__(256) void k_conv3_bww(const float* __restrict__ X, const float* __restrict__ dY, const int* __restrict__ nbr, int64_t ld,
                                                    const int* __restrict__ group_row_off, int G, int CH, float* __restrict__ slabs, int* __restrict__ slab_valid) {
-    const int co = threadIdx.x;
+    constexpr int LDA = 97;  // 96 + 1: the im2col writes walk rows (stride LDA) and must not land on one bank
+    __shared__ float As[32 * LDA];
+    __shared__ f32x4 Ds4[32 * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int i32 = lane & 31, h = lane >> 5;
     const int c = blockIdx.x;
     int g, r0, r1;
     if (!resolve_chunk(c, group_row_off, G, CH, &g, &r0, &r1)) return;
-    float acc[81];
+    for (int i = tid; i < 32 * LDA; i += 256) As[i] = 0.f;  // pad columns 81..96 stay zero
+    f32x16 acc[3];
 #pragma unroll
-    for (int i = 0; i < 81; ++i) acc[i] = 0.f;
-    for (int r = r0; r < r1; ++r) {
-        float dy = dY[(int64_t)r * 128 + co];
+    for (int m = 0; m < 3; ++m)
 #pragma unroll
-        for (int k = 0; k < 27; ++k) {
-            int nb = nbr[(int64_t)k * ld + r];  // wave-uniform
-            if (nb >= 0) {
-                const float* x = X + (int64_t)nb * 3;
-                acc[k * 3 + 0] += x[0] * dy;
-                acc[k * 3 + 1] += x[1] * dy;
-                acc[k * 3 + 2] += x[2] * dy;
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    const f32x4* D4 = (const f32x4*)dY;
+    const float* Ds = (const float*)Ds4;
+    const int sr = tid & 31, sk = tid >> 5;  // staging: row within the sub-block, offset lane (8 lanes walk the 27 offsets)
+    __syncthreads();
+    for (int rb = r0; rb < r1; rb += 32) {
+        int row = rb + sr;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            int k = sk + kk * 8;
+            if (k < 27) {
+                int nb = row < r1 ? nbr[(int64_t)k * ld + row] : -1;
+                float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+                if (nb >= 0) {
+                    const float* x = X + (int64_t)nb * 3;
+                    x0 = x[0]; x1 = x[1]; x2 = x[2];
+                }
+                As[sr * LDA + k * 3 + 0] = x0;
+                As[sr * LDA + k * 3 + 1] = x1;
+                As[sr * LDA + k * 3 + 2] = x2;
             }
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int idx = j * 256 + tid;
+            int r = idx >> 5, q = idx & 31;
+            int rr = rb + r;
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+            if (rr < r1) d = D4[(int64_t)rr * 32 + q];
+            Ds4[idx] = d;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            float b = Ds[(h * 16 + s) * 128 + wid * 32 + i32];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                float a = As[(h * 16 + s) * LDA + m * 32 + i32];
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[m], 0, 0, 0);
+            }
+        }
+        __syncthreads();
     }
     float* slab = slabs + (int64_t)c * (81 * 128);
 #pragma unroll
-    for (int i = 0; i < 81; ++i) slab[i * 128 + co] = acc[i];
-    if (co == 0) slab_valid[c] = 1;
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < 81) slab[row * 128 + wid * 32 + i32] = acc[m][r];
+        }
+    if (tid == 0) slab_valid[c] = 1;
 }
 
 __global__ void k_transpose_kernel(const float* __restrict__ W, int K, int Cin, int Cout, float* __restrict__ Wt) {
@@ -330,6 +372,13 @@ __global__ void k_transpose_kernel(const float* __restrict__ W, int K, int Cin, 
     }
 }
 
+int pick_chunk3(int64_t M) {
+    // Cin = 3: cheap chunks, aim for ~1024 of them, at least 64 rows each
+    int64_t ch = align_up64(ceil_div64(M > 0 ? M : 1, 1024), 32);
+    if (ch < 64) ch = 64;
+    return (int)ch;
+}
+
 int pick_chunk(int64_t M) {
     // about 256 row chunks per launch, at least 512 rows each, a multiple of 32
     int64_t ch = align_up64(ceil_div64(M > 0 ? M : 1, 256), 32);
@@ -339,10 +388,8 @@ int pick_chunk(int64_t M) {
 
 }  // namespace
 
-DD3D_API int dd3d_conv_chunk_rows(int64_t M) { return pick_chunk(M); }
-
 DD3D_API int64_t dd3d_conv_bwd_weight_ws_bytes(int64_t M_out, int G, int K, int Cin, int Cout) {
-    int CH = pick_chunk(M_out);
+    int CH = Cin == 3 ? pick_chunk3(M_out) : pick_chunk(M_out);
     int64_t slots = ceil_div64(M_out, CH) + G;
     int64_t nslab = (Cin == 3) ? slots : slots * K;
     int64_t per = (Cin == 3) ? (int64_t)K * 3 * Cout : (int64_t)Cin * Cout;
@@ -389,7 +436,7 @@ DD3D_API int dd3d_conv_bwd_weight(const float* X, int Cin, const float* dY, int 
     if (M_out < 0 || K != 27 || ld < M_out || Cout != 128 || (Cin != 3 && Cin != 128) || G <= 0 || !group_row_off || !dW) return DD3D_EARG;
     if (ws_bytes < dd3d_conv_bwd_weight_ws_bytes(M_out, G, K, Cin, Cout) || !ws) return DD3D_EWS;
     hipStream_t st = (hipStream_t)stream;
-    int CH = pick_chunk(M_out);
+    int CH = Cin == 3 ? pick_chunk3(M_out) : pick_chunk(M_out);
     int64_t slots = ceil_div64(M_out, CH) + G;
     int64_t nslab = (Cin == 3) ? slots : slots * K;
     int64_t per = (Cin == 3) ? (int64_t)K * 3 * Cout : (int64_t)Cin * Cout;
@@ -399,7 +446,7 @@ DD3D_API int dd3d_conv_bwd_weight(const float* X, int Cin, const float* dY, int 
     if (M_out > 0) {
         if (!X || !dY || !nbr) return DD3D_EARG;
         if (Cin == 3)
-            k_conv3_bww<<<dim3((unsigned)slots), 128, 0, st>>>(X, dY, nbr, ld, group_row_off, G, CH, slabs, valid);
+            k_conv3_bww<<<dim3((unsigned)slots), 256, 0, st>>>(X, dY, nbr, ld, group_row_off, G, CH, slabs, valid);
         else
             k_conv128_bww<<<dim3((unsigned)slots, K), 256, 0, st>>>(X, dY, nbr, ld, K, group_row_off, G, CH, slabs, valid);
     }

@@ -271,12 +271,32 @@ __global__ void k_segment_offsets(const int4* __restrict__ C, const int* m_dev, 
 
 __global__ void k_min_coord(const int4* __restrict__ C, const int* m_dev, int64_t bound, const int* __restrict__ cloud_group, int* gmin /*[G,3]*/) {
     int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x;
-    if (r >= load_count(m_dev, bound)) return;
-    int4 c = C[r];
-    int g = cloud_group ? cloud_group[c.x] : 0;
-    atomicMin(&gmin[g * 3 + 0], c.y);
-    atomicMin(&gmin[g * 3 + 1], c.z);
-    atomicMin(&gmin[g * 3 + 2], c.w);
+    const int big = 0x7F7F7F7F;
+    int g = -1, a = big, b = big, d = big;
+    if (r < load_count(m_dev, bound)) {
+        int4 c = C[r];
+        g = cloud_group ? cloud_group[c.x] : 0;
+        a = c.y; b = c.z; d = c.w;
+    }
+    // rows are grouped, so a wave almost always sees one group: reduce in the wave, one atomic per wave
+    int g0 = __builtin_amdgcn_readfirstlane(g);
+    if (__all(g == g0 || g < 0) && g0 >= 0) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            a = min(a, __shfl_xor(a, o, 64));
+            b = min(b, __shfl_xor(b, o, 64));
+            d = min(d, __shfl_xor(d, o, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&gmin[g0 * 3 + 0], a);
+            atomicMin(&gmin[g0 * 3 + 1], b);
+            atomicMin(&gmin[g0 * 3 + 2], d);
+        }
+    } else if (g >= 0) {
+        atomicMin(&gmin[g * 3 + 0], a);
+        atomicMin(&gmin[g * 3 + 1], b);
+        atomicMin(&gmin[g * 3 + 2], d);
+    }
 }
 
 // dense() placement: site[v] = ((z-minz)/ts * E1 + (y-miny)/ts) * E2 + (x-minx)/ts ; vox_at[b][site] = v

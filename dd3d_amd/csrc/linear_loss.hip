@@ -96,6 +96,36 @@ __global__ __launch_bounds__(128) void k_sl_bwd_w(const float* __restrict__ dl, 
     }
 }
 
+// site-major copy of a parameter-layout operand: out[g][s][j][c] = in[g][j][c*S + s]  (and back with inverse = 1)
+__global__ __launch_bounds__(256) void k_classifier_layout(const float* __restrict__ in, int J, int C, int S, int inverse, float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int j = blockIdx.z % J, g = blockIdx.z / J;
+    const int s0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t gbase = (int64_t)g * J * C * S;
+    if (!inverse) {
+        for (int q = ty; q < 32; q += 8) {
+            int c = c0 + q, sx = s0 + tx;
+            tile[q][tx] = (c < C && sx < S) ? in[gbase + ((int64_t)j * C + c) * S + sx] : 0.f;
+        }
+        __syncthreads();
+        for (int q = ty; q < 32; q += 8) {
+            int sx = s0 + q, c = c0 + tx;
+            if (c < C && sx < S) out[gbase + ((int64_t)sx * J + j) * C + c] = tile[tx][q];
+        }
+    } else {
+        for (int q = ty; q < 32; q += 8) {
+            int sx = s0 + q, c = c0 + tx;
+            tile[q][tx] = (c < C && sx < S) ? in[gbase + ((int64_t)sx * J + j) * C + c] : 0.f;
+        }
+        __syncthreads();
+        for (int q = ty; q < 32; q += 8) {
+            int c = c0 + q, sx = s0 + tx;
+            if (c < C && sx < S) out[gbase + ((int64_t)j * C + c) * S + sx] = tile[tx][q];
+        }
+    }
+}
+
 // ---- softmax cross-entropy over [B,J] logits, mean over the clouds of each group --------------------------------
 // per cloud: p = softmax(z), dlogits = (p - onehot)/B_g, cloud_loss = (lse - z[y])/B_g ; then one thread per group sums in order
 __global__ void k_softmax_ce(const float* __restrict__ logits, const int* __restrict__ labels, const int* __restrict__ cloud_group,
@@ -395,6 +425,14 @@ DD3D_API int dd3d_sparse_linear_bwd_w(const float* dl, const float* F, const int
 }
 
 // cloud_loss[B] is scratch; loss_g[G] (may be null) receives the mean CE of every group
+// out[g][s][j][c] = in[g][j][c*S+s] (inverse = 0) or the other way round (inverse = 1); G groups of [J, C*S]
+DD3D_API int dd3d_classifier_layout(const float* in, int G, int J, int C, int S, int inverse, float* out, void* stream) {
+    if (G <= 0 || J <= 0 || C <= 0 || S <= 0 || !in || !out || (int64_t)G * J > 65535) return DD3D_EARG;
+    k_classifier_layout<<<dim3((S + 31) / 32, (C + 31) / 32, G * J), 256, 0, (hipStream_t)stream>>>(in, J, C, S, inverse, out);
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}
+
 DD3D_API int dd3d_softmax_ce(const float* logits, const int32_t* labels, const int32_t* cloud_group, const int32_t* group_cloud_off, int G, int B, int J,
                              float* prob, float* dlogits, float* cloud_loss, float* loss_g, void* stream) {
     if (G <= 0 || J <= 0 || B < 0 || !group_cloud_off) return DD3D_EARG;

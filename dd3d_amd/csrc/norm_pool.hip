@@ -177,17 +177,24 @@ __global__ __launch_bounds__(256) void k_arp_bwd(const f32x4* __restrict__ g_poo
     }
 }
 
-// out[g][j][c4] = sum over the chunk slots of group g, slot order (deterministic); j in {0: d weight, 1: d bias}
-__global__ void k_arp_reduce(const f32x4* __restrict__ partial, const int* __restrict__ slab_valid, const int* __restrict__ group_row_off, int G, int CH,
-                             f32x4* __restrict__ gw_w, f32x4* __restrict__ gw_b) {
-    const int g = blockIdx.x, c4 = threadIdx.x & 31, j = threadIdx.x >> 5;  // 64 threads
+// out[g][j][c4] = sum over the chunk slots of group g (every slot of a group is written by k_arp_bwd); 4 slot-lanes per output sum
+// slots s = lane, lane+4, ... in order and are then combined in lane order: deterministic.  j in {0: d weight, 1: d bias}
+__global__ __launch_bounds__(256) void k_arp_reduce(const f32x4* __restrict__ partial, const int* __restrict__ group_row_off, int G, int CH,
+                                                    f32x4* __restrict__ gw_w, f32x4* __restrict__ gw_b) {
+    __shared__ f32x4 s_red[256];
+    const int g = blockIdx.x, c4 = threadIdx.x & 31, j = (threadIdx.x >> 5) & 1, sl = threadIdx.x >> 6;
     int first = 0;
     for (int q = 0; q < g; ++q) first += (group_row_off[q + 1] - group_row_off[q] + CH - 1) / CH;
     int n = (group_row_off[g + 1] - group_row_off[g] + CH - 1) / CH;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int c = first; c < first + n; ++c)
-        if (slab_valid[c]) s += partial[((int64_t)c * 2 + j) * 32 + c4];
-    (j == 0 ? gw_w : gw_b)[(int64_t)g * 32 + c4] = s;
+    for (int c = first + sl; c < first + n; c += 4) s += partial[((int64_t)c * 2 + j) * 32 + c4];
+    s_red[threadIdx.x] = s;
+    __syncthreads();
+    if (sl == 0) {
+        int t = threadIdx.x;
+        f32x4 tot = s_red[t] + s_red[t + 64] + s_red[t + 128] + s_red[t + 192];
+        (j == 0 ? gw_w : gw_b)[(int64_t)g * 32 + c4] = tot;
+    }
 }
 
 // g_xhat[i] = ga[i] * gw[group(i)]  (outer-backward seed through an affine weight gradient)
@@ -202,8 +209,8 @@ __global__ void k_scale_rows_by_group(const f32x4* __restrict__ ga, const f32x4*
 }
 
 int arp_chunk(int64_t M) {
-    int64_t ch = align_up64(ceil_div64(M > 0 ? M : 1, 2048), 8);
-    if (ch < 64) ch = 64;
+    int64_t ch = align_up64(ceil_div64(M > 0 ? M : 1, 1024), 8);
+    if (ch < 256) ch = 256;
     return (int)ch;
 }
 
@@ -285,7 +292,7 @@ DD3D_API int dd3d_affine_relu_pool_bwd(const float* g_pool, const int32_t* arg, 
                                                          (const f32x4*)b, use_affine_relu, group_row_off, G, CH, (f32x4*)g_xhat, (f32x4*)ga_out,
                                                          (const f32x4*)ga_prev, (const f32x4*)gw_extra, gw_w ? partial : nullptr, valid);
     }
-    if (gw_w) k_arp_reduce<<<dim3(G), 64, 0, st>>>(partial, valid, group_row_off, G, CH, (f32x4*)gw_w, (f32x4*)gw_b);
+    if (gw_w) k_arp_reduce<<<dim3(G), 256, 0, st>>>(partial, group_row_off, G, CH, (f32x4*)gw_w, (f32x4*)gw_b);
     DD3D_CHECK_LAUNCH();
     return 0;
 }

@@ -262,14 +262,39 @@ def _param_strides(J, C, S):
     return (ctypes.c_int64 * 4)(J * C * S, C * S, S, 1)
 
 
+def _site_strides(J, C, S):
+    import ctypes
+    return (ctypes.c_int64 * 4)(J * C * S, C, 1, J * C)
+
+
+def site_major(Wl: torch.Tensor, C: int, S: int) -> torch.Tensor:
+    """Site-major copy [.., S, J, C] of a weight-like operand in the parameter layout [.., J, C*S]: every voxel then reads its C
+    weights of one output as one contiguous 512-B row.  Cached on the tensor object (version-checked), so the frozen classifier
+    weight is converted once."""
+    hit = getattr(Wl, "_dd3d_sm", None)
+    if hit is not None and hit[0] == Wl._version and hit[1].device == Wl.device:
+        return hit[1]
+    w = _c(Wl)
+    G = w.shape[0] if w.dim() == 3 else 1
+    J = w.shape[-2]
+    out = torch.empty_like(w)
+    L.call("dd3d_classifier_layout", L.ptr(w), G, J, C, S, 0, L.ptr(out), L.stream())
+    try:
+        Wl._dd3d_sm = (Wl._version, out)
+    except Exception:
+        pass
+    return out
+
+
 class _SLFwd(Function):
     @staticmethod
     def forward(ctx, F, Wl, dp: DensePlacement):
-        f, w = _c(F), _c(Wl)
-        J = w.shape[-2] if w.dim() == 3 else w.shape[0]
+        f = _c(F)
+        w = site_major(Wl, f.shape[1], dp.S)
+        J = w.shape[-2]
         out = torch.empty((dp.B, J), dtype=_F32, device=f.device)
         L.call("dd3d_sparse_linear_fwd", L.ptr(f), L.ptr(dp.site), L.ptr(dp.seg_off), dp.B, f.shape[1], L.ptr(dp.cloud_group if w.dim() == 3 else None),
-               L.ptr(w), _param_strides(J, f.shape[1], dp.S), J, None, L.ptr(out), L.stream())
+               L.ptr(w), _site_strides(J, f.shape[1], dp.S), J, None, L.ptr(out), L.stream())
         ctx.save_for_backward(F, Wl)
         ctx.dp = dp
         return out
@@ -285,12 +310,13 @@ class _SLFwd(Function):
 class _SLBwdX(Function):
     @staticmethod
     def forward(ctx, dl, Wl, dp: DensePlacement):
-        d, w = _c(dl), _c(Wl)
+        d = _c(dl)
+        w = site_major(Wl, 128, dp.S)
         J = d.shape[1]
         M = int(dp.seg_off_rows)
         dF = torch.empty((M, 128), dtype=_F32, device=d.device)
         L.call("dd3d_sparse_linear_bwd_x", L.ptr(d), L.ptr(dp.site), L.ptr(dp.seg_off), dp.B, 128, L.ptr(dp.cloud_group if w.dim() == 3 else None),
-               L.ptr(w), _param_strides(J, 128, dp.S), J, 0, L.ptr(dF), L.stream())
+               L.ptr(w), _site_strides(J, 128, dp.S), J, 0, L.ptr(dF), L.stream())
         ctx.save_for_backward(dl, Wl)
         ctx.dp = dp
         return dF

@@ -137,6 +137,10 @@ int dd3d_sparse_linear_bwd_x(const float* dl, const int32_t* site, const int32_t
 int dd3d_sparse_linear_bwd_w(const float* dl, const float* F, const int32_t* vox_at, int S, const int32_t* group_cloud_off, int G, int C, int J,
                              float* dWl, const int64_t* strides, int64_t dWl_elems, void* stream);
 
+/* site-major copy of a [G][J, C*S] operand: out[g][s][j][c] = in[g][j][c*S+s] (inverse = 0), or back (inverse = 1).  The site-major
+ * form makes every voxel's C weights of one output contiguous (strides {J*C*S, C, 1, J*C}). */
+int dd3d_classifier_layout(const float* in, int G, int J, int C, int S, int inverse, float* out, void* stream);
+
 /* mean softmax cross-entropy per group of clouds and its first / second-order backward.
  * replaces: nn.CrossEntropyLoss + autograd, mnist_distill.py:302,344,355 */
 int dd3d_softmax_ce(const float* logits, const int32_t* labels, const int32_t* cloud_group, const int32_t* group_cloud_off, int G, int B, int J,
