@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--ipc", type=int, default=IPC)
     ap.add_argument("--metric-name", default="modmse", help="dist_opt: modmse (INI default) | ours | mse | cos")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--path", default="fused", choices=["fused", "dropin"],
+                    help="fused: class-batched step (dd3d_amd/fused_step.py); dropin: the reference-shaped autograd loop")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -72,6 +74,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from dd3d_amd.mnist_distill import Distiller
+    from dd3d_amd.fused_step import FusedDistiller
     from dd3d_amd.models.MEConv import MEConvExp
     from dd3d_amd.synthetic import init_synthetic, mnist3d_like
     from dd3d_amd import ops as _ops
@@ -81,7 +84,7 @@ def main():
     net = MEConvExp(in_channel=3, out_channel=10)
     syn = init_synthetic(NUM_CLASSES, args.ipc, NUM_POINTS, seed=0)
     my_classes = [c for c in range(NUM_CLASSES) if c % world == rank]
-    d = Distiller(images_all, indices_class, net, ipc=args.ipc, num_classes=NUM_CLASSES, num_points=NUM_POINTS, batch_size=REAL_PER_CLASS,
+    d = (FusedDistiller if args.path == "fused" else Distiller)(images_all, indices_class, net, ipc=args.ipc, num_classes=NUM_CLASSES, num_points=NUM_POINTS, batch_size=REAL_PER_CLASS,
                   dist_opt=args.metric_name, device=dev, seed=1234, image_syn=syn, classes=my_classes)
 
     # ---- live timing of the dominant kernel: the Cin=128 sparse convolution forward (fp32 MFMA) ----
@@ -104,6 +107,8 @@ def main():
 
     def one_step():
         loss = d.outer_step()
+        if timer.on and args.path == "fused":
+            nbr_keep.extend(d.last["conv1_maps"])
         if world > 1:
             torch.distributed.all_reduce(loss)  # summed matching loss (mnist_distill.py:361,373), 4 bytes over RCCL
         return loss
@@ -137,7 +142,8 @@ def main():
                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
                "data": "synthetic", "config": {"workload": f"cfg2: MNIST-3D-shaped stroke digits, {NUM_CLASSES} classes x {REAL_PER_CLASS} real clouds, "
                                                            f"ipc={args.ipc} x {NUM_POINTS} pts, MEConvExp, dist_opt={args.metric_name}",
-                                               "parallelism": f"class-sharded x{world}", "path": "drop-in autograd loop"},
+                                               "parallelism": f"class-sharded x{world}",
+                                               "path": "class-batched fused step" if args.path == "fused" else "drop-in autograd loop"},
                "loss": float(loss.item()), "roofline": roof}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(images_all, indices_class, net, syn, args)
@@ -147,24 +153,28 @@ def main():
 
 
 def cpu_baseline(images_all, indices_class, net, syn, args):
-    """The CPU oracle (torch restatement of the reference + MinkowskiEngine semantics) on the host cores, on a bounded sample of the
-    same workload: the first 2 of the 10 classes (classes are independent and equally sized), scaled to a full step."""
+    """The CPU oracle (torch restatement of the reference's step over the MinkowskiEngine restatement, oracle/) on the host cores:
+    the SAME workload (all 10 classes), one untimed warm-up step then 3 timed steps (about 10-30 s of CPU work)."""
     from oracle import ref_model as R
     import numpy as np
-    sample_classes = 2
     onet = R.MEConvExp(in_channel=3, out_channel=10)
     onet.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()})
     rng = np.random.RandomState(1234)
-    reals = [images_all[rng.permutation(indices_class[c])[:REAL_PER_CLASS]] for c in range(sample_classes)]
-    osyn = syn[: sample_classes * args.ipc].clone()
-    R.clamp_synthetic_(osyn)
+    osyn = syn.clone()
     osyn.requires_grad_()
     opt = torch.optim.SGD([osyn], lr=0.1, momentum=0.5)
-    t0 = time.perf_counter()
-    R.matching_step(onet, osyn, reals, args.ipc, args.metric_name, False, optimizer=opt)
-    t = time.perf_counter() - t0
-    return {"value": 1.0 / (t * NUM_CLASSES / sample_classes), "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{sample_classes} of {NUM_CLASSES} classes of the same workload, one step, {t:.1f} s of CPU work, scaled x{NUM_CLASSES // sample_classes}"}
+    nsteps, t = 3, 0.0
+    for it in range(nsteps + 1):
+        reals = [images_all[rng.permutation(indices_class[c])[:REAL_PER_CLASS]] for c in range(NUM_CLASSES)]
+        osyn.requires_grad_(False)
+        R.clamp_synthetic_(osyn)
+        osyn.requires_grad_()
+        t0 = time.perf_counter()
+        R.matching_step(onet, osyn, reals, args.ipc, args.metric_name, False, optimizer=opt)
+        if it > 0:
+            t += time.perf_counter() - t0
+    return {"value": nsteps / t, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{nsteps} full steps of the same workload after 1 warm-up step, {t:.1f} s of CPU work"}
 
 
 if __name__ == "__main__":

@@ -158,6 +158,16 @@ __global__ void k_group_sum(const float* __restrict__ v, const int* __restrict__
     out[g] = s;
 }
 
+// out[g][j] = sum over the clouds b of group g of v[b][j], in cloud order (deterministic)
+__global__ void k_group_sum_rows(const float* __restrict__ v, const int* __restrict__ group_cloud_off, int G, int J, float* __restrict__ out) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= G * J) return;
+    int g = t / J, j = t - g * J;
+    float s = 0.f;
+    for (int b = group_cloud_off[g]; b < group_cloud_off[g + 1]; ++b) s += v[(int64_t)b * J + j];
+    out[t] = s;
+}
+
 // second order: dlogits = (softmax(z) - onehot)/B_g ; given u = dL/d(dlogits) -> dz = p * (u - <p,u>) / B_g
 __global__ void k_softmax_ce_bwd2(const float* __restrict__ prob, const float* __restrict__ u, const int* __restrict__ group_cloud_off, int G, int J,
                                   float* __restrict__ dz) {
@@ -198,7 +208,11 @@ __global__ __launch_bounds__(256) void k_gd_stats(const GPlan p, float4* __restr
     __shared__ float4 s_half[128];
     const int item = blockIdx.x, tid = threadIdx.x;
     const int s = find_seg(p, item);
-    const dd3d_gseg sg = p.seg[s];
+    dd3d_gseg sg = p.seg[s];
+    const int64_t goff = (int64_t)blockIdx.y * sg.rows * sg.cols;  // group g: every segment tensor is [G, rows*cols]
+    sg.syn += goff;
+    sg.real += goff;
+    partial += (int64_t)blockIdx.y * p.part_off[p.n];
     const int local = item - p.item_off[s];
     const int nch = p.nchunk[s];
     if (!sg.colmajor) {
@@ -257,6 +271,9 @@ __global__ __launch_bounds__(256) void k_gd_finalize(const GPlan p, const float4
     __shared__ float4 s_tot[256];
     const int tid = threadIdx.x;
     const int total_rows = p.row_off[p.n];
+    partial += (int64_t)blockIdx.x * p.part_off[p.n];
+    stats += (int64_t)blockIdx.x * (total_rows + 1);
+    loss += blockIdx.x;
     float run = 0.f;
     float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int base = 0; base < total_rows; base += 256) {
@@ -302,12 +319,17 @@ __global__ __launch_bounds__(256) void k_gd_finalize(const GPlan p, const float4
 __global__ __launch_bounds__(256) void k_gd_bwd(const GPlan p, const float4* __restrict__ stats, const float* __restrict__ gl) {
     const int item = blockIdx.x, tid = threadIdx.x;
     const int s = find_seg(p, item);
-    const dd3d_gseg sg = p.seg[s];
+    dd3d_gseg sg = p.seg[s];
     if (!sg.dsyn) return;
+    const int64_t goff = (int64_t)blockIdx.y * sg.rows * sg.cols;
+    sg.syn += goff;
+    sg.real += goff;
+    sg.dsyn += goff;
     const int local = item - p.item_off[s];
     const int nch = p.nchunk[s];
     const float up = gl ? gl[0] : 1.0f;
     const int total_rows = p.row_off[p.n];
+    stats += (int64_t)blockIdx.y * (total_rows + 1);
     const int metric = p.metric;
     auto coef = [&](float4 st, float* ca, float* cb) {
         // d/ds [1 - <r,s>/(|r||s|+eps)] = -r/den + <r,s>*|r|/(|s|*den^2) * s
@@ -445,6 +467,13 @@ DD3D_API int dd3d_softmax_ce(const float* logits, const int32_t* labels, const i
     return 0;
 }
 
+DD3D_API int dd3d_group_sum_rows(const float* v, const int32_t* group_cloud_off, int G, int J, float* out, void* stream) {
+    if (G <= 0 || J <= 0 || !v || !group_cloud_off || !out) return DD3D_EARG;
+    k_group_sum_rows<<<dim3((G * J + 63) / 64), 64, 0, (hipStream_t)stream>>>(v, group_cloud_off, G, J, out);
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}
+
 DD3D_API int dd3d_softmax_ce_bwd2(const float* prob, const float* u, const int32_t* group_cloud_off, int G, int J, int max_clouds_per_group, float* dz,
                                   void* stream) {
     if (G <= 0 || J <= 0 || max_clouds_per_group <= 0 || !prob || !u || !group_cloud_off || !dz) return DD3D_EARG;
@@ -453,43 +482,45 @@ DD3D_API int dd3d_softmax_ce_bwd2(const float* prob, const float* u, const int32
     return 0;
 }
 
-DD3D_API int64_t dd3d_match_loss_ws_bytes(const dd3d_gseg* segs, int n) {
+DD3D_API int64_t dd3d_match_loss_ws_bytes(const dd3d_gseg* segs, int n, int G) {
     GPlan p;
-    if (build_plan(segs, n, 0, &p)) return -1;
-    return align_up64((int64_t)p.part_off[n] * 16, 256) + 256;
+    if (G <= 0 || build_plan(segs, n, 0, &p)) return -1;
+    return align_up64((int64_t)G * p.part_off[n] * 16, 256) + 256;
 }
 
-DD3D_API int64_t dd3d_match_loss_stats_floats(const dd3d_gseg* segs, int n) {
+DD3D_API int64_t dd3d_match_loss_stats_floats(const dd3d_gseg* segs, int n, int G) {
     GPlan p;
-    if (build_plan(segs, n, 0, &p)) return -1;
-    return ((int64_t)p.row_off[n] + 1) * 4;
+    if (G <= 0 || build_plan(segs, n, 0, &p)) return -1;
+    return (int64_t)G * ((int64_t)p.row_off[n] + 1) * 4;
 }
 
 // metric: 0 'ours' (distance_wb), 1 'modmse' (distance_mse), 2 'mse', 3 'cos'.  segs is a HOST array.
-DD3D_API int dd3d_match_loss_fwd(const dd3d_gseg* segs, int n, int metric, float* loss_dev, float* stats_dev, void* ws, int64_t ws_bytes, void* stream) {
+// G >= 1 independent groups: every segment tensor is [G, rows*cols] contiguous, loss_dev[G], one stats block per group.
+DD3D_API int dd3d_match_loss_fwd(const dd3d_gseg* segs, int n, int G, int metric, float* loss_dev, float* stats_dev, void* ws, int64_t ws_bytes,
+                                 void* stream) {
     GPlan p;
     int rc = build_plan(segs, n, metric, &p);
     if (rc) return rc;
-    if (!loss_dev || !stats_dev) return DD3D_EARG;
-    if (!ws || ws_bytes < dd3d_match_loss_ws_bytes(segs, n)) return DD3D_EWS;
+    if (!loss_dev || !stats_dev || G <= 0 || G > 65535) return DD3D_EARG;
+    if (!ws || ws_bytes < dd3d_match_loss_ws_bytes(segs, n, G)) return DD3D_EWS;
     hipStream_t st = (hipStream_t)stream;
     float4* partial = (float4*)ws;
-    k_gd_stats<<<dim3(p.item_off[n]), 256, 0, st>>>(p, partial);
-    k_gd_finalize<<<1, 256, 0, st>>>(p, partial, (float4*)stats_dev, loss_dev);
+    k_gd_stats<<<dim3(p.item_off[n], G), 256, 0, st>>>(p, partial);
+    k_gd_finalize<<<G, 256, 0, st>>>(p, partial, (float4*)stats_dev, loss_dev);
     DD3D_CHECK_LAUNCH();
     return 0;
 }
 
 // writes seg[i].dsyn (where non-null) = gl * d loss / d seg[i].syn ; gl_dev may be null (= 1)
-DD3D_API int dd3d_match_loss_bwd(const dd3d_gseg* segs, int n, int metric, const float* stats_dev, const float* gl_dev, void* ws, int64_t ws_bytes,
-                                 void* stream) {
+DD3D_API int dd3d_match_loss_bwd(const dd3d_gseg* segs, int n, int G, int metric, const float* stats_dev, const float* gl_dev, void* ws,
+                                 int64_t ws_bytes, void* stream) {
     GPlan p;
     int rc = build_plan(segs, n, metric, &p);
     if (rc) return rc;
-    if (!stats_dev) return DD3D_EARG;
+    if (!stats_dev || G <= 0 || G > 65535) return DD3D_EARG;
     (void)ws; (void)ws_bytes;
     hipStream_t st = (hipStream_t)stream;
-    k_gd_bwd<<<dim3(p.item_off[n]), 256, 0, st>>>(p, (const float4*)stats_dev, gl_dev);
+    k_gd_bwd<<<dim3(p.item_off[n], G), 256, 0, st>>>(p, (const float4*)stats_dev, gl_dev);
     DD3D_CHECK_LAUNCH();
     return 0;
 }

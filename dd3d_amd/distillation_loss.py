@@ -65,13 +65,13 @@ class _MatchLossChunk(Function):
         real = [_prep(t) for t in tensors[n:]]
         dev = syn[0].device
         segs = _segments(syn, real, None, layout)
-        nstats = int(L.lib.dd3d_match_loss_stats_floats(segs, n))
+        nstats = int(L.lib.dd3d_match_loss_stats_floats(segs, n, 1))
         if nstats < 0:
             raise RuntimeError("match_loss: bad segment description")
         stats = torch.empty(nstats, dtype=torch.float32, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
-        ws = L.workspace(int(L.lib.dd3d_match_loss_ws_bytes(segs, n)), dev)
-        L.call("dd3d_match_loss_fwd", segs, n, metric, L.ptr(loss), L.ptr(stats), L.ptr(ws), ws.numel(), L.stream())
+        ws = L.workspace(int(L.lib.dd3d_match_loss_ws_bytes(segs, n, 1)), dev)
+        L.call("dd3d_match_loss_fwd", segs, n, 1, metric, L.ptr(loss), L.ptr(stats), L.ptr(ws), ws.numel(), L.stream())
         ctx.saved = (syn, real, stats, layout, metric, n, [t.shape for t in tensors[:n]])
         return loss.reshape(())
 
@@ -84,7 +84,7 @@ class _MatchLossChunk(Function):
             segs = _segments(syn, real, dsyn, layout)
             glc = gl.detach().to(torch.float32).reshape(1).contiguous()
             ws = L.workspace(256, glc.device)
-            L.call("dd3d_match_loss_bwd", segs, n, metric, L.ptr(stats), L.ptr(glc), L.ptr(ws), ws.numel(), L.stream())
+            L.call("dd3d_match_loss_bwd", segs, n, 1, metric, L.ptr(stats), L.ptr(glc), L.ptr(ws), ws.numel(), L.stream())
         grads = [d.reshape(shapes[i]) if d is not None else None for i, d in enumerate(dsyn)]
         return (None, None, None, *grads, *([None] * n))
 

@@ -1,0 +1,273 @@
+"""Class-batched gradient-matching step: the same arithmetic as ``Distiller.outer_step`` (mnist_distill.py:309-374 of the reference),
+but ALL classes owned by this process go through every kernel together and nothing runs through torch autograd.
+
+Why it exists (SURVEY.md section 7 "tiny problem, big GPU"): one class is ~7k voxels at the 128-channel layer -- about a hundred
+64-row tiles for 256 CUs -- and the reference loop pays hundreds of launches plus three host syncs per class.  Classes are
+independent inside a step (mnist_distill.py:335), so a (class, cloud) batch index turns 10 small problems into one large one:
+the class of a cloud is its *group*; per-group reductions (kernel gradients, affine gradients, classifier gradients, the matching
+loss) come out of the same launches.  One device->host read per pass (row counts) is the only synchronisation.
+
+The derivative structure is the reference's: first-order sparse kernels everywhere; the second-order terms
+are exactly those that torch autograd produces around MinkowskiEngine's opaque backward passes --
+  (i)  d gw[IN weight] / d xhat  = ga (x) G            (affine product, torch-native in the reference),
+  (ii) the classifier: gw[W] = dlogits^T dense, gw[b] = sum dlogits, with dlogits = (softmax - onehot)/B differentiable through the
+       logits and ``dense`` differentiable through the whole forward graph.
+``tests/test_gpu_fused.py`` checks this path against the autograd drop-in path and against the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .distillation_loss import _METRICS, _rows_cols
+from .ops import DensePlacement, _site_strides, transposed_kernel
+from .sparse import CoordinateManager
+from .utils.Mnist2D import batch_from_images
+
+_F32, _I32 = torch.float32, torch.int32
+
+
+def _empty(shape, dev, dtype=_F32):
+    return torch.empty(shape, dtype=dtype, device=dev)
+
+
+class _Pass:
+    """Forward + first-order backward of MEConvExp over one class-batched set of clouds; keeps what the second-order pass needs."""
+
+    def __init__(self, net, coords, feats, labels, B, G, cloud_group, group_cloud_off, keep_ga: bool):
+        dev = coords.device
+        self.dev, self.B, self.G = dev, B, G
+        self.cloud_group, self.gco = cloud_group, group_cloud_off
+        st = L.stream()
+        cm = self.cm = CoordinateManager(coords, B)
+        self.N = cm.N
+        (k0, ld0), (p0, pl0) = cm.kernel_map(1, 1, 3), cm.kernel_map(1, 2, 2)
+        (k1, ld1), (p1, pl1) = cm.kernel_map(2, 2, 3), cm.kernel_map(2, 4, 2)
+        seg1, seg2 = cm.seg_off(1), cm.seg_off(2)
+        dp = self.dp = DensePlacement(cm, 4, net.dense_extent, cloud_group, G, group_cloud_off)
+        gidx = group_cloud_off.long()
+        gro1, gro2 = seg1[gidx].contiguous(), seg2[gidx].contiguous()   # rows of every group at tensor strides 1 and 2
+        cm.sync()                                                         # the ONE device->host read of this pass
+        M0, M1, M2 = cm.num_rows(1), cm.num_rows(2), cm.num_rows(4)
+        self.M = (M0, M1, M2)
+        self.maps = (k0, ld0, p0, pl0, k1, ld1, p1, pl1, seg1, seg2, gro1, gro2)
+        conv0, in0, conv1, in1 = net.features[0], net.features[1], net.features[4], net.features[5]
+        W0, W1 = conv0.kernel.detach(), conv1.kernel.detach()
+        w1, b1 = in0.weight.detach().reshape(-1), in0.bias.detach().reshape(-1)
+        w5, b5 = in1.weight.detach().reshape(-1), in1.bias.detach().reshape(-1)
+        cls_w, cls_b = net.classifier.weight, net.classifier.bias.detach()
+        J = cls_w.shape[0]
+        S = dp.S
+        self.J, self.S = J, S
+        from .ops import site_major
+        Wsm = self.Wsm = site_major(cls_w, 128, S)
+        sst = _site_strides(J, 128, S)
+        W1t = self.W1t = transposed_kernel(conv1.kernel)
+        self.params = (W0, W1, w1, b1, w5, b5)
+
+        # ---------------- forward ----------------
+        feats = feats.detach().contiguous()
+        F0 = self.F0 = _empty((M0, 3), dev)
+        L.call("dd3d_voxel_mean_fwd", L.ptr(feats), self.N, 3, L.ptr(cm.vox_off), L.ptr(cm.vox_pts), M0, L.ptr(F0), st)
+        Y0 = _empty((M0, 128), dev)
+        L.call("dd3d_conv_fwd", L.ptr(F0), M0, 3, L.ptr(W0), 128, L.ptr(k0), ld0, 27, M0, 0, L.ptr(Y0), st)
+        xh0, is0 = self.xh0, self.is0 = _empty((M0, 128), dev), _empty((B, 128), dev)
+        L.call("dd3d_inorm_fwd", L.ptr(Y0), L.ptr(seg1), B, 128, L.ptr(xh0), L.ptr(is0), st)
+        P0, arg0 = self.P0, self.arg0 = _empty((M1, 128), dev), _empty((M1, 128), dev, _I32)
+        L.call("dd3d_affine_relu_pool_fwd", L.ptr(xh0), L.ptr(w1), L.ptr(b1), 1, 128, L.ptr(p0), pl0, 8, M1, L.ptr(P0), L.ptr(arg0), st)
+        Y1 = _empty((M1, 128), dev)
+        L.call("dd3d_conv_fwd", L.ptr(P0), M1, 128, L.ptr(W1), 128, L.ptr(k1), ld1, 27, M1, 0, L.ptr(Y1), st)
+        xh1, is1 = self.xh1, self.is1 = _empty((M1, 128), dev), _empty((B, 128), dev)
+        L.call("dd3d_inorm_fwd", L.ptr(Y1), L.ptr(seg2), B, 128, L.ptr(xh1), L.ptr(is1), st)
+        P1, arg1 = self.P1, self.arg1 = _empty((M2, 128), dev), _empty((M2, 128), dev, _I32)
+        L.call("dd3d_affine_relu_pool_fwd", L.ptr(xh1), L.ptr(w5), L.ptr(b5), 1, 128, L.ptr(p1), pl1, 8, M2, L.ptr(P1), L.ptr(arg1), st)
+        logits = self.logits = _empty((B, J), dev)
+        L.call("dd3d_sparse_linear_fwd", L.ptr(P1), L.ptr(dp.site), L.ptr(dp.seg_off), B, 128, None, L.ptr(Wsm), sst, J, L.ptr(cls_b),
+               L.ptr(logits), st)
+        prob, dl = self.prob, self.dl = _empty((B, J), dev), _empty((B, J), dev)
+        closs, self.ce = _empty((B,), dev), _empty((G,), dev)
+        L.call("dd3d_softmax_ce", L.ptr(logits), L.ptr(labels), L.ptr(cloud_group), L.ptr(group_cloud_off), G, B, J, L.ptr(prob), L.ptr(dl),
+               L.ptr(closs), L.ptr(self.ce), st)
+
+        # ---------------- first-order backward: one gradient list per group ----------------
+        g_cb = _empty((G, J), dev)
+        L.call("dd3d_group_sum_rows", L.ptr(dl), L.ptr(group_cloud_off), G, J, L.ptr(g_cb), st)
+        g_cw = _empty((G, J, 128 * S), dev)
+        pst = (ctypes.c_int64 * 4)(J * 128 * S, 128 * S, S, 1)
+        L.call("dd3d_sparse_linear_bwd_w", L.ptr(dl), L.ptr(P1), L.ptr(dp.vox_at), S, L.ptr(group_cloud_off), G, 128, J, L.ptr(g_cw), pst,
+               g_cw.numel(), st)
+        gP1 = _empty((M2, 128), dev)
+        L.call("dd3d_sparse_linear_bwd_x", L.ptr(dl), L.ptr(dp.site), L.ptr(dp.seg_off), B, 128, None, L.ptr(Wsm), sst, J, 0, L.ptr(gP1), st)
+        gx1, self.ga1, g_w5, g_b5 = self._arp_bwd(gP1, arg1, cm.parent(4), xh1, w5, b5, gro2, M1, keep_ga, True)
+        gY1 = _empty((M1, 128), dev)
+        L.call("dd3d_inorm_bwd", L.ptr(gx1), L.ptr(xh1), L.ptr(is1), L.ptr(seg2), B, 128, L.ptr(gY1), st)
+        g_W1 = self._bww(P0, 128, gY1, k1, ld1, M1, gro2)
+        gP0 = _empty((M1, 128), dev)
+        L.call("dd3d_conv_bwd_data", L.ptr(gY1), M1, 128, L.ptr(W1t), 128, L.ptr(k1), ld1, 27, L.ptr(gP0), st)
+        gx0, self.ga0, g_w1, g_b1 = self._arp_bwd(gP0, arg0, cm.parent(2), xh0, w1, b1, gro1, M0, keep_ga, True)
+        gY0 = _empty((M0, 128), dev)
+        L.call("dd3d_inorm_bwd", L.ptr(gx0), L.ptr(xh0), L.ptr(is0), L.ptr(seg1), B, 128, L.ptr(gY0), st)
+        g_W0 = self._bww(F0, 3, gY0, k0, ld0, M0, gro1)
+        # order of network.parameters()
+        self.gw = [g_W0, g_w1, g_b1, g_W1, g_w5, g_b5, g_cw, g_cb]
+
+    def _arp_bwd(self, g_pool, arg, parent, xhat, w, b, gro, M_in, keep_ga, want_gw, ga_prev=None, gw_extra=None):
+        dev, G = self.dev, self.G
+        gx = _empty((M_in, 128), dev)
+        ga = _empty((M_in, 128), dev) if keep_ga else None
+        gw_w = _empty((G, 128), dev) if want_gw else None
+        gw_b = _empty((G, 128), dev) if want_gw else None
+        ws = L.workspace(int(L.lib.dd3d_arp_bwd_ws_bytes(M_in, G)), dev)
+        L.call("dd3d_affine_relu_pool_bwd", L.ptr(g_pool), L.ptr(arg), L.ptr(parent), L.ptr(xhat), L.ptr(w), L.ptr(b), 1, 128, M_in, L.ptr(gro), G,
+               L.ptr(gx), L.ptr(ga), L.ptr(ga_prev), L.ptr(gw_extra), L.ptr(gw_w), L.ptr(gw_b), L.ptr(ws), ws.numel(), L.stream())
+        return gx, ga, gw_w, gw_b
+
+    def _bww(self, X, Cin, dY, nbr, ld, M, gro):
+        G = self.G
+        dW = _empty((G, 27, Cin, 128), self.dev)
+        ws = L.workspace(int(L.lib.dd3d_conv_bwd_weight_ws_bytes(M, G, 27, Cin, 128)), self.dev)
+        L.call("dd3d_conv_bwd_weight", L.ptr(X), Cin, L.ptr(dY), 128, L.ptr(nbr), ld, 27, M, L.ptr(gro), G, L.ptr(dW), L.ptr(ws), ws.numel(),
+               L.stream())
+        return dW
+
+    # ---------------- second-order backward into the point features (synthetic pass only) ----------------
+    def backward_to_points(self, G_w1, G_w5, G_cw, G_cb):
+        """d(sum_g matching loss) / d feats [N,3], given its gradients w.r.t. the four differentiable entries of gw_syn."""
+        dev, B, G, J, S = self.dev, self.B, self.G, self.J, self.S
+        M0, M1, M2 = self.M
+        k0, ld0, p0, pl0, k1, ld1, p1, pl1, seg1, seg2, gro1, gro2 = self.maps
+        W0, W1, w1, b1, w5, b5 = self.params
+        dp, cm, st = self.dp, self.cm, L.stream()
+        sst = _site_strides(J, 128, S)
+        Gsm = _empty((G, S, J, 128), dev)
+        L.call("dd3d_classifier_layout", L.ptr(G_cw), G, J, 128, S, 0, L.ptr(Gsm), st)
+        # u = dL/d(dlogits): through gw[W] = dlogits^T dense and gw[b] = sum dlogits
+        u = _empty((B, J), dev)
+        L.call("dd3d_sparse_linear_fwd", L.ptr(self.P1), L.ptr(dp.site), L.ptr(dp.seg_off), B, 128, L.ptr(self.cloud_group), L.ptr(Gsm), sst, J,
+               None, L.ptr(u), st)
+        u += G_cb[self.cloud_group.long()]
+        dz = _empty((B, J), dev)
+        per = int((self.gco[1:] - self.gco[:-1]).max().item()) if self._max_per is None else self._max_per
+        L.call("dd3d_softmax_ce_bwd2", L.ptr(self.prob), L.ptr(u), L.ptr(self.gco), G, J, per, L.ptr(dz), st)
+        # H = dL/dP1: through dense in gw[W] (weights G_cw, coefficients dlogits) and through the logits (weights W, coefficients dz)
+        H = _empty((M2, 128), dev)
+        L.call("dd3d_sparse_linear_bwd_x", L.ptr(self.dl), L.ptr(dp.site), L.ptr(dp.seg_off), B, 128, L.ptr(self.cloud_group), L.ptr(Gsm), sst, J,
+               0, L.ptr(H), st)
+        L.call("dd3d_sparse_linear_bwd_x", L.ptr(dz), L.ptr(dp.site), L.ptr(dp.seg_off), B, 128, None, L.ptr(self.Wsm), sst, J, 1, L.ptr(H), st)
+        hx1, _, _, _ = self._arp_bwd(H, self.arg1, cm.parent(4), self.xh1, w5, b5, gro2, M1, False, False, self.ga1, G_w5)
+        hY1 = _empty((M1, 128), dev)
+        L.call("dd3d_inorm_bwd", L.ptr(hx1), L.ptr(self.xh1), L.ptr(self.is1), L.ptr(seg2), B, 128, L.ptr(hY1), st)
+        hP0 = _empty((M1, 128), dev)
+        L.call("dd3d_conv_bwd_data", L.ptr(hY1), M1, 128, L.ptr(self.W1t), 128, L.ptr(k1), ld1, 27, L.ptr(hP0), st)
+        hx0, _, _, _ = self._arp_bwd(hP0, self.arg0, cm.parent(2), self.xh0, w1, b1, gro1, M0, False, False, self.ga0, G_w1)
+        hY0 = _empty((M0, 128), dev)
+        L.call("dd3d_inorm_bwd", L.ptr(hx0), L.ptr(self.xh0), L.ptr(self.is0), L.ptr(seg1), B, 128, L.ptr(hY0), st)
+        hF0 = _empty((M0, 3), dev)
+        L.call("dd3d_conv_bwd_data", L.ptr(hY0), M0, 128, L.ptr(W0), 3, L.ptr(k0), ld0, 27, L.ptr(hF0), st)
+        dfeats = _empty((self.N, 3), dev)
+        L.call("dd3d_voxel_mean_bwd", L.ptr(hF0), M0, 3, L.ptr(cm.levels[1].inv), L.ptr(cm.vox_off), self.N, L.ptr(dfeats), st)
+        return dfeats
+
+    _max_per: Optional[int] = None
+
+
+def grouped_match_loss(gw_syn: List[torch.Tensor], gw_real: List[torch.Tensor], dis_metric: str, G: int, need_grad, pyt: bool = False):
+    """distillation_loss.match_loss for G classes at once: tensors are [G, *param_shape]; returns (loss[G], grads list)."""
+    if dis_metric not in _METRICS:
+        exit("unknown distance function: %s" % dis_metric)
+    metric = _METRICS[dis_metric]
+    n = len(gw_syn)
+    dev = gw_syn[0].device
+    layout = [_rows_cols(tuple(t.shape[1:]), pyt) for t in gw_real]
+    if metric in (2, 3):
+        layout = [(1, r * c, 0) for (r, c, _) in layout]
+    dsyn = [torch.empty_like(s) if need_grad[i] else None for i, s in enumerate(gw_syn)]
+    segs = (L.GSeg * n)()
+    for i in range(n):
+        segs[i].syn, segs[i].real = gw_syn[i].data_ptr(), gw_real[i].data_ptr()
+        segs[i].dsyn = dsyn[i].data_ptr() if dsyn[i] is not None else None
+        segs[i].rows, segs[i].cols, segs[i].colmajor = layout[i]
+    stats = _empty((int(L.lib.dd3d_match_loss_stats_floats(segs, n, G)),), dev)
+    loss = _empty((G,), dev)
+    ws = L.workspace(int(L.lib.dd3d_match_loss_ws_bytes(segs, n, G)), dev)
+    L.call("dd3d_match_loss_fwd", segs, n, G, metric, L.ptr(loss), L.ptr(stats), L.ptr(ws), ws.numel(), L.stream())
+    L.call("dd3d_match_loss_bwd", segs, n, G, metric, L.ptr(stats), None, L.ptr(ws), ws.numel(), L.stream())
+    return loss, dsyn
+
+
+class FusedDistiller:
+    """Same constructor and state as ``mnist_distill.Distiller`` (MEConvExp only); ``outer_step`` runs the class-batched path."""
+
+    def __init__(self, images_all, indices_class, network, ipc, num_classes=10, num_points=250, batch_size=256, dist_opt="modmse",
+                 dist_lr=0.1, device=None, seed=0, image_syn=None, classes=None, momentum=0.5):
+        self.device = dev = torch.device(device or "cuda")
+        self.images_all = images_all.to(dev)
+        self.indices_class = [np.asarray(ix) for ix in indices_class]
+        self.network = network.to(dev).train()
+        self.num_classes, self.ipc, self.num_points, self.batch_size = num_classes, ipc, num_points, batch_size
+        self.dist_opt, self.rng = dist_opt, np.random.RandomState(seed)
+        self.classes = list(range(num_classes)) if classes is None else list(classes)
+        if image_syn is None:
+            g = torch.Generator().manual_seed(seed)
+            image_syn = 28 * torch.rand((num_classes * ipc, num_points, 3), generator=g, dtype=torch.float)
+        self.image_syn = image_syn.to(dev).clone().contiguous()
+        self.momentum_buf = torch.zeros_like(self.image_syn)
+        self.lr, self.momentum, self.steps_done = dist_lr, momentum, 0
+        G = self.G = len(self.classes)
+        cls = torch.tensor(self.classes, device=dev)
+        # rows of image_syn owned by this process, class-major
+        self.syn_rows = (cls[:, None] * ipc + torch.arange(ipc, device=dev)[None, :]).reshape(-1)
+        self.syn_labels = cls.repeat_interleave(ipc).to(_I32)
+        self.syn_group = torch.arange(G, device=dev, dtype=_I32).repeat_interleave(ipc)
+        self.syn_gco = (torch.arange(G + 1, device=dev) * ipc).to(_I32)
+        self.syn_batch_col = torch.arange(G * ipc, device=dev, dtype=_F32).repeat_interleave(num_points)[:, None]
+        self.last = {}
+
+    def clamp(self):
+        s = self.image_syn
+        s.clamp_(0, 27)
+        s[:, :, 0] = 0
+
+    def sample_real(self):
+        """mnist_distill.py:200-208 for every owned class at once: one gather + one nonzero."""
+        idx = np.concatenate([self.rng.permutation(self.indices_class[c])[:self.batch_size] for c in self.classes])
+        sizes = [min(self.batch_size, len(self.indices_class[c])) for c in self.classes]
+        return self.real_batch_from_images(self.images_all[torch.as_tensor(idx, device=self.device)], sizes)
+
+    def real_batch_from_images(self, images, sizes):
+        dev = self.device
+        labels = torch.tensor(np.repeat(self.classes, sizes), device=dev)
+        b = batch_from_images(images, labels, self.num_points)
+        b["cloud_group"] = torch.tensor(np.repeat(np.arange(self.G), sizes), device=dev, dtype=_I32)
+        b["group_cloud_off"] = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), device=dev, dtype=_I32)
+        b["max_per"] = int(max(sizes))
+        return b
+
+    def outer_step(self, real_batch=None, apply_update=True):
+        dev, G, ipc, npts = self.device, self.G, self.ipc, self.num_points
+        self.clamp()
+        rb = real_batch if real_batch is not None else self.sample_real()
+        B_r = int(rb["num_clouds"])
+        real = _Pass(self.network, rb["coordinates"], rb["features"], rb["labels"].to(_I32), B_r, G, rb["cloud_group"], rb["group_cloud_off"], False)
+        xyz = self.image_syn[self.syn_rows].reshape(-1, 3)           # [G*ipc*npts, 3]; coordinates and features are the same tensor
+        coords = torch.cat([self.syn_batch_col, xyz], 1)
+        syn = _Pass(self.network, coords, xyz, self.syn_labels, G * ipc, G, self.syn_group, self.syn_gco, True)
+        syn._max_per = ipc
+        # only these entries of gw_syn depend on the synthetic points: IN weights, classifier weight and bias
+        need = [False, True, False, False, True, False, True, True]
+        loss_g, d = grouped_match_loss(syn.gw, real.gw, self.dist_opt, G, need)
+        dfeats = syn.backward_to_points(d[1], d[4], d[6], d[7])
+        grad = torch.zeros_like(self.image_syn)
+        grad[self.syn_rows] = dfeats.reshape(G * ipc, npts, 3)
+        self.last = {"per_class": loss_g, "grad": grad, "gw_real": real.gw, "gw_syn": syn.gw, "logits": (real.logits, syn.logits),
+                     "conv1_maps": [(real.maps[4], real.M[1]), (syn.maps[4], syn.M[1])], "rows": (real.M, syn.M)}
+        if apply_update:
+            n = self.image_syn.numel()
+            L.call("dd3d_sgd_momentum_clamp", L.ptr(self.image_syn), L.ptr(grad), L.ptr(self.momentum_buf), n, self.lr, self.momentum,
+                   1 if self.steps_done == 0 else 0, 0, 0.0, 27.0, L.stream())
+            self.steps_done += 1
+        return loss_g.sum()

@@ -145,6 +145,7 @@ int dd3d_classifier_layout(const float* in, int G, int J, int C, int S, int inve
  * replaces: nn.CrossEntropyLoss + autograd, mnist_distill.py:302,344,355 */
 int dd3d_softmax_ce(const float* logits, const int32_t* labels, const int32_t* cloud_group, const int32_t* group_cloud_off, int G, int B, int J,
                     float* prob, float* dlogits, float* cloud_loss, float* loss_g, void* stream);
+int dd3d_group_sum_rows(const float* v, const int32_t* group_cloud_off, int G, int J, float* out, void* stream);
 int dd3d_softmax_ce_bwd2(const float* prob, const float* u, const int32_t* group_cloud_off, int G, int J, int max_clouds_per_group, float* dz,
                          void* stream);
 
@@ -169,12 +170,14 @@ typedef struct dd3d_gseg {
     int32_t pad_;
 } dd3d_gseg;
 
-/* segs is a HOST array of n <= DD3D_MAX_SEG descriptors.  stats_dev needs dd3d_match_loss_stats_floats() floats and is kept for the
- * backward.  loss_dev[1]. */
-int64_t dd3d_match_loss_ws_bytes(const dd3d_gseg* segs, int n);
-int64_t dd3d_match_loss_stats_floats(const dd3d_gseg* segs, int n);
-int dd3d_match_loss_fwd(const dd3d_gseg* segs, int n, int metric, float* loss_dev, float* stats_dev, void* ws, int64_t ws_bytes, void* stream);
-int dd3d_match_loss_bwd(const dd3d_gseg* segs, int n, int metric, const float* stats_dev, const float* gl_dev, void* ws, int64_t ws_bytes,
+/* segs is a HOST array of n <= DD3D_MAX_SEG descriptors.  G >= 1 independent groups (classes): every segment tensor is
+ * [G, rows*cols] contiguous and loss_dev has G entries (one matching loss per class).  stats_dev needs
+ * dd3d_match_loss_stats_floats() floats and is kept for the backward. */
+int64_t dd3d_match_loss_ws_bytes(const dd3d_gseg* segs, int n, int G);
+int64_t dd3d_match_loss_stats_floats(const dd3d_gseg* segs, int n, int G);
+int dd3d_match_loss_fwd(const dd3d_gseg* segs, int n, int G, int metric, float* loss_dev, float* stats_dev, void* ws, int64_t ws_bytes,
+                        void* stream);
+int dd3d_match_loss_bwd(const dd3d_gseg* segs, int n, int G, int metric, const float* stats_dev, const float* gl_dev, void* ws, int64_t ws_bytes,
                         void* stream);
 
 /* x -= lr * (mom = first_step ? grad : momentum*mom + grad); optional clamp to [lo,hi] with column 0 of every xyz row forced to 0.

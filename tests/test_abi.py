@@ -34,7 +34,7 @@ def test_size_queries_are_pure_host_functions():
     assert _lib.lib.dd3d_unique_ws_bytes(1000, cap) > 0
     assert _lib.lib.dd3d_conv_bwd_weight_ws_bytes(7000, 1, 27, 128, 128) > 0
     seg = (_lib.GSeg * 1)()
-    assert _lib.lib.dd3d_match_loss_ws_bytes(seg, 1) == -1  # null pointers are an argument error, not a crash
+    assert _lib.lib.dd3d_match_loss_ws_bytes(seg, 1, 1) == -1  # null pointers are an argument error, not a crash
 
 
 def test_gseg_struct_layout_matches_header():
