@@ -299,9 +299,9 @@ __global__ void k_min_coord(const int4* __restrict__ C, const int* m_dev, int64_
     }
 }
 
-// dense() placement: site[v] = ((z-minz)/ts * E1 + (y-miny)/ts) * E2 + (x-minx)/ts ; vox_at[b][site] = v
+// dense() placement: site[v] = ((z-minz)/ts * E1 + (y-miny)/ts) * E2 + (x-minx)/ts ; vox_at[site][b] = v (site-major: the clouds of one site are contiguous)
 __global__ void k_dense_sites(const int4* __restrict__ C, const int* m_dev, int64_t bound, const int* __restrict__ cloud_group, const int* __restrict__ gmin,
-                              int ts, int E0, int E1, int E2, int* __restrict__ site, int* __restrict__ vox_at, int* err) {
+                              int ts, int E0, int E1, int E2, int B, int* __restrict__ site, int* __restrict__ vox_at, int* err) {
     int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x;
     if (r >= load_count(m_dev, bound)) return;
     int4 c = C[r];
@@ -314,7 +314,7 @@ __global__ void k_dense_sites(const int4* __restrict__ C, const int* m_dev, int6
     }
     int s = (a * E1 + b) * E2 + d;
     site[r] = s;
-    if (vox_at) vox_at[(int64_t)c.x * (E0 * E1 * E2) + s] = (int)r;
+    if (vox_at) vox_at[(int64_t)s * B + c.x] = (int)r;
 }
 
 inline dim3 grid1(int64_t n) { return dim3((unsigned)ceil_div64(n > 0 ? n : 1, TB)); }
@@ -477,9 +477,9 @@ DD3D_API int dd3d_segment_offsets(const int32_t* C, const int32_t* m_dev, int64_
 }
 
 // dense() placement of the last sparse tensor (models/MEConv.py:250-254): per-group minimum corner, site index per voxel,
-// and the inverse table vox_at[B][E0*E1*E2] (-1 = no voxel).  cloud_group may be null (one group).
+// and the inverse table vox_at[E0*E1*E2][B] (-1 = no voxel).  cloud_group may be null (one group).
 DD3D_API int dd3d_dense_sites(const int32_t* C, const int32_t* m_dev, int64_t bound, const int32_t* cloud_group, int G, int B, int tensor_stride,
-                              int E0, int E1, int E2, int32_t* gmin /*[G,3]*/, int32_t* site /*[bound]*/, int32_t* vox_at /*[B,S] or null*/,
+                              int E0, int E1, int E2, int32_t* gmin /*[G,3]*/, int32_t* site /*[bound]*/, int32_t* vox_at /*[S,B] or null*/,
                               int32_t* err_dev, void* stream) {
     if (bound < 0 || G <= 0 || B < 0 || tensor_stride <= 0 || E0 <= 0 || E1 <= 0 || E2 <= 0 || !gmin || !err_dev) return DD3D_EARG;
     hipStream_t st = (hipStream_t)stream;
@@ -488,7 +488,7 @@ DD3D_API int dd3d_dense_sites(const int32_t* C, const int32_t* m_dev, int64_t bo
     if (bound == 0) return 0;
     if (!C || !site) return DD3D_EARG;
     k_min_coord<<<grid1(bound), TB, 0, st>>>((const int4*)C, m_dev, bound, cloud_group, gmin);
-    k_dense_sites<<<grid1(bound), TB, 0, st>>>((const int4*)C, m_dev, bound, cloud_group, gmin, tensor_stride, E0, E1, E2, site, vox_at, err_dev);
+    k_dense_sites<<<grid1(bound), TB, 0, st>>>((const int4*)C, m_dev, bound, cloud_group, gmin, tensor_stride, E0, E1, E2, B, site, vox_at, err_dev);
     DD3D_CHECK_LAUNCH();
     return 0;
 }

@@ -18,29 +18,53 @@ struct WStride {
     int64_t g, j, c, s;
 };
 
+// one workgroup per cloud; wave w takes voxels w, w+4, ...: the voxel's 128 features sit in the wave (float2 per lane) and are dotted
+// with the J weight rows of its site -- J independent 512-B loads in flight per voxel; lane j keeps output j's running sum.
 __global__ __launch_bounds__(256) void k_sl_fwd(const float* __restrict__ F, const int* __restrict__ site, const int* __restrict__ seg_off,
                                                 const int* __restrict__ cloud_group, const float* __restrict__ Wl, WStride ws, int J,
                                                 const float* __restrict__ bias, float* __restrict__ out) {
-    __shared__ float s_part[64 * 4];
-    const int b = blockIdx.x, tid = threadIdx.x, c = tid & 127, rl = tid >> 7, lane = tid & 63, wid = tid >> 6;
+    __shared__ float s_part[4][64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r0 = seg_off[b], r1 = seg_off[b + 1];
     const int g = cloud_group ? cloud_group[b] : 0;
-    const float* Wg = Wl + g * ws.g + c * ws.c;
+    const float* Wg = Wl + g * ws.g;
+    const bool unit_c = ws.c == 1;
     for (int j0 = 0; j0 < J; j0 += 64) {
-        int jn = min(64, J - j0);
-        for (int jj = 0; jj < jn; ++jj) {
-            const float* Wj = Wg + (int64_t)(j0 + jj) * ws.j;
-            float acc = 0.f;
-            for (int v = r0 + rl; v < r1; v += 2) {
-                int s = site[v];
-                if (s >= 0) acc += F[(int64_t)v * 128 + c] * Wj[s * ws.s];
+        const int jn = min(64, J - j0);
+        float acc = 0.f;
+        for (int v = r0 + wid; v < r1; v += 4) {
+            const int s = site[v];
+            if (s < 0) continue;
+            const float2 f = *(const float2*)(F + (int64_t)v * 128 + lane * 2);
+            const float* Ws = Wg + s * ws.s;
+            for (int jb = 0; jb < jn; jb += 8) {
+                float p[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    p[u] = 0.f;
+                    if (jb + u < jn) {
+                        const float* Wj = Ws + (int64_t)(j0 + jb + u) * ws.j;
+                        float w0, w1;
+                        if (unit_c) {
+                            float2 w = *(const float2*)(Wj + lane * 2);
+                            w0 = w.x; w1 = w.y;
+                        } else {
+                            w0 = Wj[(int64_t)(lane * 2) * ws.c]; w1 = Wj[(int64_t)(lane * 2 + 1) * ws.c];
+                        }
+                        p[u] = f.x * w0 + f.y * w1;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    float t = wave_sum(p[u]);
+                    if (lane == jb + u) acc += t;
+                }
             }
-            acc = wave_sum(acc);
-            if (lane == 0) s_part[jj * 4 + wid] = acc;
         }
+        s_part[wid][lane] = acc;
         __syncthreads();
         if (tid < jn) {
-            float s = s_part[tid * 4] + s_part[tid * 4 + 1] + s_part[tid * 4 + 2] + s_part[tid * 4 + 3];
+            float s = s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid];
             if (bias) s += bias[j0 + tid];
             out[(int64_t)b * J + j0 + tid] = s;
         }
@@ -68,31 +92,47 @@ __global__ __launch_bounds__(256) void k_sl_bwd_x(const float* __restrict__ dl, 
     }
 }
 
-// grid (S, G); 128 threads = channels; writes only the sites some cloud of the group occupies (the caller zero-fills the rest)
-__global__ __launch_bounds__(128) void k_sl_bwd_w(const float* __restrict__ dl, const float* __restrict__ F, const int* __restrict__ vox_at, int S,
+// grid (S, G): one workgroup per (site, group); 8 cloud-lanes x 32 float4 channel-lanes.  Only sites that some cloud of the group
+// occupies are written (the caller zero-fills the rest).  Cloud-lane partial sums are combined in lane order: deterministic.
+__global__ __launch_bounds__(256) void k_sl_bwd_w(const float* __restrict__ dl, const float* __restrict__ F, const int* __restrict__ vox_at, int S, int B,
                                                   const int* __restrict__ group_cloud_off, int J, float* __restrict__ dWl, WStride ws) {
-    const int s = blockIdx.x, g = blockIdx.y, c = threadIdx.x;
+    __shared__ f32x4 s_red[8 * 32];
+    const int s = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, c4 = tid & 31, bl = tid >> 5;
     const int b0 = group_cloud_off[g], b1 = group_cloud_off[g + 1];
+    const int* va = vox_at + (int64_t)s * B;
     int any = 0;
-    for (int b = b0 + c; b < b1; b += 128) any |= vox_at[(int64_t)b * S + s] >= 0;
+    for (int b = b0 + tid; b < b1; b += 256) any |= va[b] >= 0;
     if (!__syncthreads_or(any)) return;
-    float* out = dWl + g * ws.g + c * ws.c + s * ws.s;
-    for (int j0 = 0; j0 < J; j0 += 8) {
-        float acc[8];
+    const f32x4* F4 = (const f32x4*)F;
+    float* out = dWl + g * ws.g + s * ws.s;
+    for (int j0 = 0; j0 < J; j0 += 16) {
+        f32x4 acc[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc[u] = 0.f;
-        for (int b = b0; b < b1; ++b) {
-            int v = vox_at[(int64_t)b * S + s];  // wave-uniform
+        for (int u = 0; u < 16; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int b = b0 + bl; b < b1; b += 8) {
+            int v = va[b];
             if (v < 0) continue;
-            float f = F[(int64_t)v * 128 + c];
+            f32x4 f = F4[(int64_t)v * 32 + c4];
             const float* d = dl + (int64_t)b * J + j0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < 16; ++u)
                 if (j0 + u < J) acc[u] += d[u] * f;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (j0 + u < J) out[(int64_t)(j0 + u) * ws.j] = acc[u];
+        for (int u = 0; u < 16; ++u) {
+            if (j0 + u >= J) break;
+            s_red[bl * 32 + c4] = acc[u];
+            __syncthreads();
+            if (bl == 0) {
+                f32x4 t = s_red[c4];
+#pragma unroll
+                for (int q = 1; q < 8; ++q) t += s_red[q * 32 + c4];
+                float* o = out + (int64_t)(j0 + u) * ws.j;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[(int64_t)(c4 * 4 + e) * ws.c] = t[e];
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -435,13 +475,13 @@ DD3D_API int dd3d_sparse_linear_bwd_x(const float* dl, const int32_t* site, cons
 }
 
 // dWl must hold G * strides[0] floats (or J*C*S when G == 1); it is zero-filled here, then the occupied sites are written.
-DD3D_API int dd3d_sparse_linear_bwd_w(const float* dl, const float* F, const int32_t* vox_at, int S, const int32_t* group_cloud_off, int G, int C, int J,
-                                      float* dWl, const int64_t* strides, int64_t dWl_elems, void* stream) {
-    if (G <= 0 || C != 128 || J <= 0 || S <= 0 || !strides || !dWl || !group_cloud_off || dWl_elems < (int64_t)J * C * S) return DD3D_EARG;
+DD3D_API int dd3d_sparse_linear_bwd_w(const float* dl, const float* F, const int32_t* vox_at, int S, int B, const int32_t* group_cloud_off, int G, int C,
+                                      int J, float* dWl, const int64_t* strides, int64_t dWl_elems, void* stream) {
+    if (G <= 0 || B < 0 || C != 128 || J <= 0 || S <= 0 || !strides || !dWl || !group_cloud_off || dWl_elems < (int64_t)J * C * S) return DD3D_EARG;
     hipStream_t st = (hipStream_t)stream;
     DD3D_HIP(hipMemsetAsync(dWl, 0, dWl_elems * 4, st));
     if (!dl || !F || !vox_at) return DD3D_EARG;
-    k_sl_bwd_w<<<dim3(S, G), 128, 0, st>>>(dl, F, vox_at, S, group_cloud_off, J, dWl, mk_stride(strides));
+    if (B > 0) k_sl_bwd_w<<<dim3(S, G), 256, 0, st>>>(dl, F, vox_at, S, B, group_cloud_off, J, dWl, mk_stride(strides));
     DD3D_CHECK_LAUNCH();
     return 0;
 }

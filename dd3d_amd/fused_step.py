@@ -98,7 +98,7 @@ class _Pass:
         L.call("dd3d_group_sum_rows", L.ptr(dl), L.ptr(group_cloud_off), G, J, L.ptr(g_cb), st)
         g_cw = _empty((G, J, 128 * S), dev)
         pst = (ctypes.c_int64 * 4)(J * 128 * S, 128 * S, S, 1)
-        L.call("dd3d_sparse_linear_bwd_w", L.ptr(dl), L.ptr(P1), L.ptr(dp.vox_at), S, L.ptr(group_cloud_off), G, 128, J, L.ptr(g_cw), pst,
+        L.call("dd3d_sparse_linear_bwd_w", L.ptr(dl), L.ptr(P1), L.ptr(dp.vox_at), S, B, L.ptr(group_cloud_off), G, 128, J, L.ptr(g_cw), pst,
                g_cw.numel(), st)
         gP1 = _empty((M2, 128), dev)
         L.call("dd3d_sparse_linear_bwd_x", L.ptr(dl), L.ptr(dp.site), L.ptr(dp.seg_off), B, 128, None, L.ptr(Wsm), sst, J, 0, L.ptr(gP1), st)

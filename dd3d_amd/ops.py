@@ -247,7 +247,7 @@ class DensePlacement:
         self.S = self.E[0] * self.E[1] * self.E[2]
         bound = cm._rows_bound(lv)
         self.site = torch.empty(max(bound, 1), dtype=torch.int32, device=dev)
-        self.vox_at = torch.empty((max(self.B, 1), self.S), dtype=torch.int32, device=dev)
+        self.vox_at = torch.empty((self.S, max(self.B, 1)), dtype=torch.int32, device=dev)
         self.gmin = torch.empty((G, 3), dtype=torch.int32, device=dev)
         self.cloud_group = cloud_group
         self.group_cloud_off = group_cloud_off if group_cloud_off is not None else torch.tensor([0, self.B], dtype=torch.int32, device=dev)
@@ -338,7 +338,7 @@ class _SLBwdW(Function):
         shape = (G, J, C * dp.S) if grouped else (J, C * dp.S)
         dW = torch.empty(shape, dtype=_F32, device=d.device)
         gco = dp.group_cloud_off if grouped else dp.whole_batch_off
-        L.call("dd3d_sparse_linear_bwd_w", L.ptr(d), L.ptr(f), L.ptr(dp.vox_at), dp.S, L.ptr(gco), G, C, J, L.ptr(dW), _param_strides(J, C, dp.S),
+        L.call("dd3d_sparse_linear_bwd_w", L.ptr(d), L.ptr(f), L.ptr(dp.vox_at), dp.S, dp.B, L.ptr(gco), G, C, J, L.ptr(dW), _param_strides(J, C, dp.S),
                dW.numel(), L.stream())
         ctx.save_for_backward(dl, F)
         ctx.dp, ctx.grouped = dp, grouped

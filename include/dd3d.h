@@ -70,7 +70,7 @@ int dd3d_kernel_map_pairs(const int32_t* nbr, int64_t ld, const int32_t* m_dev, 
 int dd3d_segment_offsets(const int32_t* C, const int32_t* m_dev, int64_t bound, int B, int32_t* seg_off, int32_t* err_dev, void* stream);
 
 /* Placement used by SparseTensor.dense(shape=[B,128,E0,E1,E2], min_coordinate=batch minimum), models/MEConv.py:250-254:
- * gmin[G,3] per-group minimum corner, site[v] = flat (E0,E1,E2) index of voxel v, vox_at[B][E0*E1*E2] inverse table (nullable).
+ * gmin[G,3] per-group minimum corner, site[v] = flat (E0,E1,E2) index of voxel v, vox_at[E0*E1*E2][B] inverse table (site-major, nullable).
  * cloud_group[B] (nullable = one group).  *err_dev |= 2 if a voxel falls outside the extent (ME raises there). */
 int dd3d_dense_sites(const int32_t* C, const int32_t* m_dev, int64_t bound, const int32_t* cloud_group, int G, int B, int tensor_stride,
                      int E0, int E1, int E2, int32_t* gmin, int32_t* site, int32_t* vox_at, int32_t* err_dev, void* stream);
@@ -134,7 +134,7 @@ int dd3d_sparse_linear_fwd(const float* F, const int32_t* site, const int32_t* s
                            const int64_t* strides, int J, const float* bias, float* out, void* stream);
 int dd3d_sparse_linear_bwd_x(const float* dl, const int32_t* site, const int32_t* seg_off, int B, int C, const int32_t* cloud_group, const float* Wl,
                              const int64_t* strides, int J, int accumulate, float* dF, void* stream);
-int dd3d_sparse_linear_bwd_w(const float* dl, const float* F, const int32_t* vox_at, int S, const int32_t* group_cloud_off, int G, int C, int J,
+int dd3d_sparse_linear_bwd_w(const float* dl, const float* F, const int32_t* vox_at, int S, int B, const int32_t* group_cloud_off, int G, int C, int J,
                              float* dWl, const int64_t* strides, int64_t dWl_elems, void* stream);
 
 /* site-major copy of a [G][J, C*S] operand: out[g][s][j][c] = in[g][j][c*S+s] (inverse = 0), or back (inverse = 1).  The site-major
