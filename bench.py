@@ -83,7 +83,8 @@ def main():
     images_all, _labels, indices_class = mnist3d_like(NUM_CLASSES, POOL_PER_CLASS, seed=0)
     net = MEConvExp(in_channel=3, out_channel=10)
     syn = init_synthetic(NUM_CLASSES, args.ipc, NUM_POINTS, seed=0)
-    my_classes = [c for c in range(NUM_CLASSES) if c % world == rank]
+    from dd3d_amd.sharding import max_over_ranks, owned_classes, reduce_loss
+    my_classes = owned_classes(NUM_CLASSES, rank, world)
     d = (FusedDistiller if args.path == "fused" else Distiller)(images_all, indices_class, net, ipc=args.ipc, num_classes=NUM_CLASSES, num_points=NUM_POINTS, batch_size=REAL_PER_CLASS,
                   dist_opt=args.metric_name, device=dev, seed=1234, image_syn=syn, classes=my_classes)
 
@@ -109,9 +110,7 @@ def main():
         loss = d.outer_step()
         if timer.on and args.path == "fused":
             nbr_keep.extend(d.last["conv1_maps"])
-        if world > 1:
-            torch.distributed.all_reduce(loss)  # summed matching loss (mnist_distill.py:361,373), 4 bytes over RCCL
-        return loss
+        return reduce_loss(loss)  # summed matching loss (mnist_distill.py:361,373): 4 bytes over RCCL when world > 1
 
     for _ in range(args.warmup):
         one_step()
@@ -123,10 +122,7 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     timer.on = False
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(dt, dev)
 
     if rank == 0:
         ms = [e0.elapsed_time(e1) for (e0, e1, _a) in timer.records]
@@ -154,7 +150,7 @@ def main():
 
 def cpu_baseline(images_all, indices_class, net, syn, args):
     """The CPU oracle (torch restatement of the reference's step over the MinkowskiEngine restatement, oracle/) on the host cores:
-    the SAME workload (all 10 classes), one untimed warm-up step then 3 timed steps (about 10-30 s of CPU work)."""
+    the SAME workload (all 10 classes), one untimed warm-up step then 8 timed steps (about 10-30 s of CPU work)."""
     from oracle import ref_model as R
     import numpy as np
     onet = R.MEConvExp(in_channel=3, out_channel=10)
@@ -163,7 +159,7 @@ def cpu_baseline(images_all, indices_class, net, syn, args):
     osyn = syn.clone()
     osyn.requires_grad_()
     opt = torch.optim.SGD([osyn], lr=0.1, momentum=0.5)
-    nsteps, t = 3, 0.0
+    nsteps, t = 8, 0.0
     for it in range(nsteps + 1):
         reals = [images_all[rng.permutation(indices_class[c])[:REAL_PER_CLASS]] for c in range(NUM_CLASSES)]
         osyn.requires_grad_(False)
