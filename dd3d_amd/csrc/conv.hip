@@ -126,8 +126,11 @@ __global__ __launch_bounds__(256) void k_conv128(const float* __restrict__ X, co
 __global__ __launch_bounds__(256) void k_conv128_bww(const float* __restrict__ X, const float* __restrict__ dY, const int* __restrict__ nbr, int64_t ld,
                                                      int K, const int* __restrict__ group_row_off, int G, int CH, float* __restrict__ slabs,
                                                      int* __restrict__ slab_valid) {
+    // The (in,out) pairs of offset k inside the chunk are first COMPACTED (stable ballot scan, 1024 rows per window), so the matrix
+    // cores only see rows that have a neighbour; the contraction then runs over 32 pairs at a time.
     __shared__ f32x4 As4[32 * 32];
     __shared__ f32x4 Ds4[32 * 32];
+    __shared__ int s_row[1024], s_nb[1024], s_wc[4];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int i32 = lane & 31, h = lane >> 5;
     const int wm0 = (wid >> 1) * 64, wn0 = (wid & 1) * 64;
@@ -135,9 +138,6 @@ __global__ __launch_bounds__(256) void k_conv128_bww(const float* __restrict__ X
     int g, r0, r1;
     if (!resolve_chunk(c, group_row_off, G, CH, &g, &r0, &r1)) return;
     const int* nk = nbr + (int64_t)k * ld;
-    int any = 0;
-    for (int r = r0 + tid; r < r1; r += 256) any |= nk[r] >= 0;
-    if (!__syncthreads_or(any)) return;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -150,25 +150,48 @@ __global__ __launch_bounds__(256) void k_conv128_bww(const float* __restrict__ X
     const f32x4* D4 = (const f32x4*)dY;
     const float* As = (const float*)As4;
     const float* Ds = (const float*)Ds4;
+    bool have_any = false;
 
-    for (int rb = r0; rb < r1; rb += 32) {
-        int have = 0;
+    for (int wb = r0; wb < r1; wb += 1024) {
+        int total = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            int idx = j * 256 + tid;
-            int r = idx >> 5, q = idx & 31;
-            int row = rb + r;
+            int row = wb + j * 256 + tid;
             int nb = row < r1 ? nk[row] : -1;
-            f32x4 a = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
-            if (nb >= 0) {
-                a = X4[(int64_t)nb * 32 + q];
-                d = D4[(int64_t)row * 32 + q];
-                have = 1;
+            unsigned long long bal = __ballot(nb >= 0);
+            if (lane == 0) s_wc[wid] = __popcll(bal);
+            __syncthreads();
+            int base = total, all = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                int x = s_wc[w];
+                if (w < wid) base += x;
+                all += x;
             }
-            As4[idx] = a;
-            Ds4[idx] = d;
+            if (nb >= 0) {
+                int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+                s_row[pos] = row;
+                s_nb[pos] = nb;
+            }
+            total += all;
+            __syncthreads();
         }
-        if (__syncthreads_or(have)) {
+        if (total) have_any = true;
+        for (int sb = 0; sb < total; sb += 32) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int idx = j * 256 + tid;
+                int r = idx >> 5, q = idx & 31;
+                int e = sb + r;
+                f32x4 a = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
+                if (e < total) {
+                    a = X4[(int64_t)s_nb[e] * 32 + q];
+                    d = D4[(int64_t)s_row[e] * 32 + q];
+                }
+                As4[idx] = a;
+                Ds4[idx] = d;
+            }
+            __syncthreads();
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 float a[2], b[2];
@@ -181,9 +204,10 @@ __global__ __launch_bounds__(256) void k_conv128_bww(const float* __restrict__ X
 #pragma unroll
                     for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
+    if (!have_any) return;
     float* slab = slabs + ((int64_t)c * K + k) * (128 * 128);
 #pragma unroll
     for (int m = 0; m < 2; ++m)
