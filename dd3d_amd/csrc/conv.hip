@@ -66,47 +66,71 @@ __global__ __launch_bounds__(256) void k_conv128(const float* __restrict__ X, co
     const f32x4* W4 = (const f32x4*)W;
     const float* Bs = (const float*)Bs4;
 
-    for (int k = 0; k < K; ++k) {
-        if (!((kmask >> k) & 1u)) continue;
-        const bool wave_on = (wmask >> k) & 1u;
-        for (int kc = 0; kc < 4; ++kc) {
-            // ---- stage the gathered A tile [TM][32] and the W[k] slice [32][128] ----
+    // Steps = (offset with a neighbour in this tile) x (four 32-channel chunks).  The global loads of step s+1 are issued into registers
+    // BEFORE the MFMAs of step s and written to LDS after them, so their latency hides under the matrix work.
+    f32x4 ra[TM / 32], rb[4];
+    auto load_regs = [&](int k, int kc) {
 #pragma unroll
-            for (int j = 0; j < TM / 32; ++j) {
-                int idx = j * 256 + tid;
-                int r = idx >> 3, q = idx & 7;
-                int nb = s_nbr[k * TM + r];
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (nb >= 0) v = X4[(int64_t)nb * 32 + kc * 8 + q];
-                As4[r * LDA4 + q] = v;
-            }
+        for (int j = 0; j < TM / 32; ++j) {
+            int idx = j * 256 + tid;
+            int nb = s_nbr[k * TM + (idx >> 3)];
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (nb >= 0) v = X4[(int64_t)nb * 32 + kc * 8 + (idx & 7)];
+            ra[j] = v;
+        }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int idx = j * 256 + tid;
-                int kr = idx >> 5, q = idx & 31;
-                Bs4[idx] = W4[((int64_t)k * 128 + kc * 32 + kr) * 32 + q];
-            }
-            __syncthreads();
-            if (wave_on) {
-                f32x4 a[MT][4];
+        for (int j = 0; j < 4; ++j) {
+            int idx = j * 256 + tid;
+            rb[j] = W4[((int64_t)k * 128 + kc * 32 + (idx >> 5)) * 32 + (idx & 31)];
+        }
+    };
+    auto store_regs = [&]() {
+#pragma unroll
+        for (int j = 0; j < TM / 32; ++j) {
+            int idx = j * 256 + tid;
+            As4[(idx >> 3) * LDA4 + (idx & 7)] = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Bs4[j * 256 + tid] = rb[j];
+    };
+    int k = kmask ? __builtin_ctz(kmask) : -1, kc = 0;
+    if (k >= 0) {
+        load_regs(k, 0);
+        store_regs();
+        __syncthreads();
+    }
+    while (k >= 0) {
+        int nk = k, nkc = kc + 1;
+        if (nkc == 4) {
+            nkc = 0;
+            unsigned rest = k + 1 < 32 ? kmask >> (k + 1) : 0u;
+            nk = rest ? k + 1 + __builtin_ctz(rest) : -1;
+        }
+        if (nk >= 0) load_regs(nk, nkc);
+        if ((wmask >> k) & 1u) {
+            f32x4 a[MT][4];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[m][j] = As4[(wrow0 + m * 32 + i32) * LDA4 + h * 4 + j];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                float b[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) b[n] = Bs[(h * 16 + s) * 128 + wcol0 + n * 32 + i32];
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) a[m][j] = As4[(wrow0 + m * 32 + i32) * LDA4 + h * 4 + j];
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    float b[NT];
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) b[n] = Bs[(h * 16 + s) * 128 + wcol0 + n * 32 + i32];
-#pragma unroll
-                    for (int m = 0; m < MT; ++m)
-#pragma unroll
-                        for (int n = 0; n < NT; ++n)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][s >> 2][s & 3], b[n], acc[m][n], 0, 0, 0);
-                }
+                    for (int n = 0; n < NT; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][s >> 2][s & 3], b[n], acc[m][n], 0, 0, 0);
             }
-            __syncthreads();
         }
+        __syncthreads();
+        if (nk < 0) break;
+        store_regs();
+        __syncthreads();
+        k = nk;
+        kc = nkc;
     }
     // ---- epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
 #pragma unroll

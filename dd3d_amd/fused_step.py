@@ -38,20 +38,28 @@ def _empty(shape, dev, dtype=_F32):
 class _Pass:
     """Forward + first-order backward of MEConvExp over one class-batched set of clouds; keeps what the second-order pass needs."""
 
-    def __init__(self, net, coords, feats, labels, B, G, cloud_group, group_cloud_off, keep_ga: bool):
+    def __init__(self, net, coords, B, G, cloud_group, group_cloud_off):
+        """Phase 1 (no host sync): every coordinate map of the pass, enqueued on the current stream."""
         dev = coords.device
-        self.dev, self.B, self.G = dev, B, G
+        self.dev, self.B, self.G, self.net = dev, B, G, net
         self.cloud_group, self.gco = cloud_group, group_cloud_off
-        st = L.stream()
         cm = self.cm = CoordinateManager(coords, B)
         self.N = cm.N
-        (k0, ld0), (p0, pl0) = cm.kernel_map(1, 1, 3), cm.kernel_map(1, 2, 2)
-        (k1, ld1), (p1, pl1) = cm.kernel_map(2, 2, 3), cm.kernel_map(2, 4, 2)
+        k0, p0 = cm.kernel_map(1, 1, 3), cm.kernel_map(1, 2, 2)
+        k1, p1 = cm.kernel_map(2, 2, 3), cm.kernel_map(2, 4, 2)
         seg1, seg2 = cm.seg_off(1), cm.seg_off(2)
-        dp = self.dp = DensePlacement(cm, 4, net.dense_extent, cloud_group, G, group_cloud_off)
+        self.dp = DensePlacement(cm, 4, net.dense_extent, cloud_group, G, group_cloud_off)
         gidx = group_cloud_off.long()
         gro1, gro2 = seg1[gidx].contiguous(), seg2[gidx].contiguous()   # rows of every group at tensor strides 1 and 2
-        cm.sync()                                                         # the ONE device->host read of this pass
+        self._pre = (k0, p0, k1, p1, seg1, seg2, gro1, gro2)
+
+    def run(self, feats, labels, keep_ga: bool):
+        """Phase 2: ONE device->host read (row counts), then forward + first-order backward on the current stream."""
+        net, dev, B, G, cm, dp = self.net, self.dev, self.B, self.G, self.cm, self.dp
+        cloud_group, group_cloud_off = self.cloud_group, self.gco
+        (k0, ld0), (p0, pl0), (k1, ld1), (p1, pl1), seg1, seg2, gro1, gro2 = self._pre
+        st = L.stream()
+        cm.sync()
         M0, M1, M2 = cm.num_rows(1), cm.num_rows(2), cm.num_rows(4)
         self.M = (M0, M1, M2)
         self.maps = (k0, ld0, p0, pl0, k1, ld1, p1, pl1, seg1, seg2, gro1, gro2)
@@ -114,6 +122,7 @@ class _Pass:
         g_W0 = self._bww(F0, 3, gY0, k0, ld0, M0, gro1)
         # order of network.parameters()
         self.gw = [g_W0, g_w1, g_b1, g_W1, g_w5, g_b5, g_cw, g_cb]
+        return self
 
     def _arp_bwd(self, g_pool, arg, parent, xhat, w, b, gro, M_in, keep_ga, want_gw, ga_prev=None, gw_extra=None):
         dev, G = self.dev, self.G
@@ -226,6 +235,9 @@ class FusedDistiller:
         self.syn_gco = (torch.arange(G + 1, device=dev) * ipc).to(_I32)
         self.syn_batch_col = torch.arange(G * ipc, device=dev, dtype=_F32).repeat_interleave(num_points)[:, None]
         self.last = {}
+        # the real and the synthetic pass are independent until the loss: they run on two streams, so the small synthetic kernels and
+        # both chains of latency-bound map kernels overlap with the large real-batch kernels
+        self.stream_real, self.stream_syn = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
 
     def clamp(self):
         s = self.image_syn
@@ -252,11 +264,28 @@ class FusedDistiller:
         self.clamp()
         rb = real_batch if real_batch is not None else self.sample_real()
         B_r = int(rb["num_clouds"])
-        real = _Pass(self.network, rb["coordinates"], rb["features"], rb["labels"].to(_I32), B_r, G, rb["cloud_group"], rb["group_cloud_off"], False)
+        rlabels = rb["labels"].to(_I32)
         xyz = self.image_syn[self.syn_rows].reshape(-1, 3)           # [G*ipc*npts, 3]; coordinates and features are the same tensor
         coords = torch.cat([self.syn_batch_col, xyz], 1)
-        syn = _Pass(self.network, coords, xyz, self.syn_labels, G * ipc, G, self.syn_group, self.syn_gco, True)
+        # cached layouts of the frozen weights are (re)built here, on the main stream, before the two passes fork
+        from .ops import site_major
+        net = self.network
+        site_major(net.classifier.weight, 128, net.dense_extent[0] * net.dense_extent[1] * net.dense_extent[2])
+        transposed_kernel(net.features[4].kernel)
+        main, sr, ss = torch.cuda.current_stream(dev), self.stream_real, self.stream_syn
+        sr.wait_stream(main)
+        ss.wait_stream(main)
+        with torch.cuda.stream(sr):
+            real = _Pass(self.network, rb["coordinates"], B_r, G, rb["cloud_group"], rb["group_cloud_off"])
+        with torch.cuda.stream(ss):
+            syn = _Pass(self.network, coords, G * ipc, G, self.syn_group, self.syn_gco)
+        with torch.cuda.stream(sr):
+            real.run(rb["features"], rlabels, False)
+        with torch.cuda.stream(ss):
+            syn.run(xyz, self.syn_labels, True)
         syn._max_per = ipc
+        main.wait_stream(sr)
+        main.wait_stream(ss)
         # only these entries of gw_syn depend on the synthetic points: IN weights, classifier weight and bias
         need = [False, True, False, False, True, False, True, True]
         loss_g, d = grouped_match_loss(syn.gw, real.gw, self.dist_opt, G, need)
