@@ -238,6 +238,8 @@ class FusedDistiller:
         # the real and the synthetic pass are independent until the loss: they run on two streams, so the small synthetic kernels and
         # both chains of latency-bound map kernels overlap with the large real-batch kernels
         self.stream_real, self.stream_syn = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        # next step's real batch is sampled on its own stream while this step's kernels run (it depends on nothing the step computes)
+        self.stream_data, self._prefetched = torch.cuda.Stream(dev), None
 
     def clamp(self):
         s = self.image_syn
@@ -262,7 +264,14 @@ class FusedDistiller:
     def outer_step(self, real_batch=None, apply_update=True):
         dev, G, ipc, npts = self.device, self.G, self.ipc, self.num_points
         self.clamp()
-        rb = real_batch if real_batch is not None else self.sample_real()
+        main = torch.cuda.current_stream(dev)
+        if real_batch is not None:
+            rb = real_batch
+        elif self._prefetched is not None:
+            rb, self._prefetched = self._prefetched, None
+            main.wait_stream(self.stream_data)
+        else:
+            rb = self.sample_real()
         B_r = int(rb["num_clouds"])
         rlabels = rb["labels"].to(_I32)
         xyz = self.image_syn[self.syn_rows].reshape(-1, 3)           # [G*ipc*npts, 3]; coordinates and features are the same tensor
@@ -272,9 +281,12 @@ class FusedDistiller:
         net = self.network
         site_major(net.classifier.weight, 128, net.dense_extent[0] * net.dense_extent[1] * net.dense_extent[2])
         transposed_kernel(net.features[4].kernel)
-        main, sr, ss = torch.cuda.current_stream(dev), self.stream_real, self.stream_syn
+        sr, ss = self.stream_real, self.stream_syn
         sr.wait_stream(main)
         ss.wait_stream(main)
+        for t in rb.values():
+            if torch.is_tensor(t):
+                t.record_stream(sr)
         with torch.cuda.stream(sr):
             real = _Pass(self.network, rb["coordinates"], B_r, G, rb["cloud_group"], rb["group_cloud_off"])
         with torch.cuda.stream(ss):
@@ -299,4 +311,8 @@ class FusedDistiller:
             L.call("dd3d_sgd_momentum_clamp", L.ptr(self.image_syn), L.ptr(grad), L.ptr(self.momentum_buf), n, self.lr, self.momentum,
                    1 if self.steps_done == 0 else 0, 0, 0.0, 27.0, L.stream())
             self.steps_done += 1
-        return loss_g.sum()
+        total = loss_g.sum()
+        if real_batch is None:
+            with torch.cuda.stream(self.stream_data):
+                self._prefetched = self.sample_real()
+        return total
