@@ -18,50 +18,48 @@ struct WStride {
     int64_t g, j, c, s;
 };
 
-// one workgroup per cloud; wave w takes voxels w, w+4, ...: the voxel's 128 features sit in the wave (float2 per lane) and are dotted
-// with the J weight rows of its site -- J independent 512-B loads in flight per voxel; lane j keeps output j's running sum.
+// one workgroup per cloud; wave w takes voxels w, w+4, ...: the voxel's 128 features sit in the wave (float2 per lane) and are
+// multiplied into per-lane partial sums for up to 16 outputs at a time (16 independent 512-B weight rows in flight per voxel);
+// the 64-lane reductions happen once per output after the voxel loop, not per voxel.
 __global__ __launch_bounds__(256) void k_sl_fwd(const float* __restrict__ F, const int* __restrict__ site, const int* __restrict__ seg_off,
                                                 const int* __restrict__ cloud_group, const float* __restrict__ Wl, WStride ws, int J,
                                                 const float* __restrict__ bias, float* __restrict__ out) {
-    __shared__ float s_part[4][64];
+    __shared__ float s_part[4][16];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r0 = seg_off[b], r1 = seg_off[b + 1];
     const int g = cloud_group ? cloud_group[b] : 0;
     const float* Wg = Wl + g * ws.g;
     const bool unit_c = ws.c == 1;
-    for (int j0 = 0; j0 < J; j0 += 64) {
-        const int jn = min(64, J - j0);
-        float acc = 0.f;
+    for (int j0 = 0; j0 < J; j0 += 16) {
+        const int jn = min(16, J - j0);
+        float acc[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc[u] = 0.f;
         for (int v = r0 + wid; v < r1; v += 4) {
             const int s = site[v];
             if (s < 0) continue;
             const float2 f = *(const float2*)(F + (int64_t)v * 128 + lane * 2);
-            const float* Ws = Wg + s * ws.s;
-            for (int jb = 0; jb < jn; jb += 8) {
-                float p[8];
+            const float* Ws = Wg + s * ws.s + (int64_t)j0 * ws.j;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    p[u] = 0.f;
-                    if (jb + u < jn) {
-                        const float* Wj = Ws + (int64_t)(j0 + jb + u) * ws.j;
-                        float w0, w1;
-                        if (unit_c) {
-                            float2 w = *(const float2*)(Wj + lane * 2);
-                            w0 = w.x; w1 = w.y;
-                        } else {
-                            w0 = Wj[(int64_t)(lane * 2) * ws.c]; w1 = Wj[(int64_t)(lane * 2 + 1) * ws.c];
-                        }
-                        p[u] = f.x * w0 + f.y * w1;
+            for (int u = 0; u < 16; ++u) {
+                if (u < jn) {
+                    const float* Wj = Ws + (int64_t)u * ws.j;
+                    float w0, w1;
+                    if (unit_c) {
+                        float2 w = *(const float2*)(Wj + lane * 2);
+                        w0 = w.x; w1 = w.y;
+                    } else {
+                        w0 = Wj[(int64_t)(lane * 2) * ws.c]; w1 = Wj[(int64_t)(lane * 2 + 1) * ws.c];
                     }
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    float t = wave_sum(p[u]);
-                    if (lane == jb + u) acc += t;
+                    acc[u] += f.x * w0 + f.y * w1;
                 }
             }
         }
-        s_part[wid][lane] = acc;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            float t = wave_sum(acc[u]);
+            if (lane == u) s_part[wid][u] = t;
+        }
         __syncthreads();
         if (tid < jn) {
             float s = s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid];

@@ -28,7 +28,19 @@ __global__ void k_voxel_mean_bwd(const float* __restrict__ dF0, int C, const int
     dfeats[t] = dF0[(int64_t)v * C + c] / (float)(vox_off[v + 1] - vox_off[v]);
 }
 
-// ---- instance norm: one workgroup per cloud, 8 row-lanes x 32 float4 channel-lanes -----------
+// ---- instance norm: grid (cloud, channel quarter); a workgroup = 32 row-lanes x 8 float4 channel-lanes (128-B row segments) ------
+__device__ __forceinline__ f32x4 quarter_colsum(f32x4 v, f32x4* s_red /*[32*8]*/) {
+    const int c = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    s_red[rl * 8 + c] = v;
+    __syncthreads();
+    f32x4 s = s_red[c];
+#pragma unroll
+    for (int j = 1; j < 32; ++j) s += s_red[j * 8 + c];
+    __syncthreads();
+    return s;
+}
+
+// 8 row-lanes x 32 float4 channel-lanes (whole 512-B rows), used by the pooling backward
 __device__ __forceinline__ f32x4 block_colsum(f32x4 v, f32x4* s_red /*[8*32]*/) {
     const int c4 = threadIdx.x & 31, rl = threadIdx.x >> 5;
     s_red[rl * 32 + c4] = v;
@@ -43,7 +55,7 @@ __device__ __forceinline__ f32x4 block_colsum(f32x4 v, f32x4* s_red /*[8*32]*/) 
 __global__ __launch_bounds__(256) void k_inorm_fwd(const f32x4* __restrict__ Y, const int* __restrict__ seg_off, f32x4* __restrict__ xhat,
                                                    f32x4* __restrict__ inv_std) {
     __shared__ f32x4 s_red[256];
-    const int b = blockIdx.x, c4 = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int b = blockIdx.x, c4 = blockIdx.y * 8 + (threadIdx.x & 7), rl = threadIdx.x >> 3;
     const int r0 = seg_off[b], r1 = seg_off[b + 1];
     const int n = r1 - r0;
     if (n <= 0) {
@@ -51,39 +63,39 @@ __global__ __launch_bounds__(256) void k_inorm_fwd(const f32x4* __restrict__ Y, 
         return;
     }
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int r = r0 + rl; r < r1; r += 8) s += Y[(int64_t)r * 32 + c4];
-    f32x4 mean = block_colsum(s, s_red) / (float)n;
+    for (int r = r0 + rl; r < r1; r += 32) s += Y[(int64_t)r * 32 + c4];
+    f32x4 mean = quarter_colsum(s, s_red) / (float)n;
     f32x4 q = {0.f, 0.f, 0.f, 0.f};
-    for (int r = r0 + rl; r < r1; r += 8) {
+    for (int r = r0 + rl; r < r1; r += 32) {
         f32x4 d = Y[(int64_t)r * 32 + c4] - mean;
         q += d * d;
     }
-    f32x4 var = block_colsum(q, s_red) / (float)n;
+    f32x4 var = quarter_colsum(q, s_red) / (float)n;
     f32x4 is;
 #pragma unroll
     for (int j = 0; j < 4; ++j) is[j] = 1.0f / sqrtf(var[j] + 1e-8f);
     if (rl == 0) inv_std[(int64_t)b * 32 + c4] = is;
-    for (int r = r0 + rl; r < r1; r += 8) xhat[(int64_t)r * 32 + c4] = (Y[(int64_t)r * 32 + c4] - mean) * is;
+    for (int r = r0 + rl; r < r1; r += 32) xhat[(int64_t)r * 32 + c4] = (Y[(int64_t)r * 32 + c4] - mean) * is;
 }
 
 // dY = (g - xhat * mean(g*xhat) - mean(g)) * inv_std     (MinkowskiInstanceNormFunction.backward)
 __global__ __launch_bounds__(256) void k_inorm_bwd(const f32x4* __restrict__ g, const f32x4* __restrict__ xhat, const f32x4* __restrict__ inv_std,
                                                    const int* __restrict__ seg_off, f32x4* __restrict__ dY) {
     __shared__ f32x4 s_red[256];
-    const int b = blockIdx.x, c4 = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int b = blockIdx.x, c4 = blockIdx.y * 8 + (threadIdx.x & 7), rl = threadIdx.x >> 3;
     const int r0 = seg_off[b], r1 = seg_off[b + 1];
     const int n = r1 - r0;
     if (n <= 0) return;
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-    for (int r = r0 + rl; r < r1; r += 8) {
+    for (int r = r0 + rl; r < r1; r += 32) {
         f32x4 gg = g[(int64_t)r * 32 + c4];
         s1 += gg;
         s2 += gg * xhat[(int64_t)r * 32 + c4];
     }
-    f32x4 m1 = block_colsum(s1, s_red) / (float)n;
-    f32x4 m2 = block_colsum(s2, s_red) / (float)n;
+    f32x4 m1 = quarter_colsum(s1, s_red) / (float)n;
+    f32x4 m2 = quarter_colsum(s2, s_red) / (float)n;
     f32x4 is = inv_std[(int64_t)b * 32 + c4];
-    for (int r = r0 + rl; r < r1; r += 8) {
+    for (int r = r0 + rl; r < r1; r += 32) {
         int64_t o = (int64_t)r * 32 + c4;
         dY[o] = (g[o] - xhat[o] * m2 - m1) * is;
     }
@@ -210,7 +222,7 @@ __global__ void k_scale_rows_by_group(const f32x4* __restrict__ ga, const f32x4*
 
 int arp_chunk(int64_t M) {
     int64_t ch = align_up64(ceil_div64(M > 0 ? M : 1, 1024), 8);
-    if (ch < 256) ch = 256;
+    if (ch < 64) ch = 64;
     return (int)ch;
 }
 
@@ -240,7 +252,7 @@ DD3D_API int dd3d_inorm_fwd(const float* Y, const int32_t* seg_off, int B, int C
     if (B < 0 || C != 128) return DD3D_EARG;
     if (B == 0) return 0;
     if (!Y || !seg_off || !xhat || !inv_std) return DD3D_EARG;
-    k_inorm_fwd<<<dim3(B), 256, 0, (hipStream_t)stream>>>((const f32x4*)Y, seg_off, (f32x4*)xhat, (f32x4*)inv_std);
+    k_inorm_fwd<<<dim3(B, 4), 256, 0, (hipStream_t)stream>>>((const f32x4*)Y, seg_off, (f32x4*)xhat, (f32x4*)inv_std);
     DD3D_CHECK_LAUNCH();
     return 0;
 }
@@ -249,7 +261,7 @@ DD3D_API int dd3d_inorm_bwd(const float* g, const float* xhat, const float* inv_
     if (B < 0 || C != 128) return DD3D_EARG;
     if (B == 0) return 0;
     if (!g || !xhat || !inv_std || !seg_off || !dY) return DD3D_EARG;
-    k_inorm_bwd<<<dim3(B), 256, 0, (hipStream_t)stream>>>((const f32x4*)g, (const f32x4*)xhat, (const f32x4*)inv_std, seg_off, (f32x4*)dY);
+    k_inorm_bwd<<<dim3(B, 4), 256, 0, (hipStream_t)stream>>>((const f32x4*)g, (const f32x4*)xhat, (const f32x4*)inv_std, seg_off, (f32x4*)dY);
     DD3D_CHECK_LAUNCH();
     return 0;
 }
