@@ -40,16 +40,17 @@ _SIGS = {
     "dd3d_kernel_map_pairs": (I32, [P, I64, P, I64, I32, P, P, P, P, I64, P]),
     "dd3d_segment_offsets": (I32, [P, P, I64, I32, P, P, P]),
     "dd3d_dense_sites": (I32, [P, P, I64, P, I32, I32, I32, I32, I32, I32, P, P, P, P, P]),
-    "dd3d_conv_fwd": (I32, [P, I64, I32, P, I32, P, I64, I32, I64, I32, P, P]),
-    "dd3d_conv_bwd_data": (I32, [P, I64, I32, P, I32, P, I64, I32, P, P]),
+    "dd3d_gather_clouds": (I32, [P, P, I32, P, I32, I32, I64, P, P, P, P, P, P]),
+    "dd3d_conv_fwd": (I32, [P, I64, I32, P, I32, P, I64, I32, I64, P, I32, P, P]),
+    "dd3d_conv_bwd_data": (I32, [P, I64, P, I32, P, I32, P, I64, I32, P, P]),
     "dd3d_conv_bwd_weight_ws_bytes": (I64, [I64, I32, I32, I32, I32]),
     "dd3d_conv_bwd_weight": (I32, [P, I32, P, I32, P, I64, I32, I64, P, I32, P, P, I64, P]),
     "dd3d_transpose_kernel": (I32, [P, I32, I32, I32, P, P]),
-    "dd3d_voxel_mean_fwd": (I32, [P, I64, I32, P, P, I64, P, P]),
+    "dd3d_voxel_mean_fwd": (I32, [P, I64, I32, P, P, I64, P, P, P]),
     "dd3d_voxel_mean_bwd": (I32, [P, I64, I32, P, P, I64, P, P]),
     "dd3d_inorm_fwd": (I32, [P, P, I32, I32, P, P, P]),
     "dd3d_inorm_bwd": (I32, [P, P, P, P, I32, I32, P, P]),
-    "dd3d_affine_relu_pool_fwd": (I32, [P, P, P, I32, I32, P, I64, I32, I64, P, P, P]),
+    "dd3d_affine_relu_pool_fwd": (I32, [P, P, P, I32, I32, P, I64, I32, I64, P, P, P, P]),
     "dd3d_arp_bwd_ws_bytes": (I64, [I64, I32]),
     "dd3d_affine_relu_pool_bwd": (I32, [P, P, P, P, P, P, I32, I32, I64, P, I32, P, P, P, P, P, P, P, I64, P]),
     "dd3d_scale_rows_by_group": (I32, [P, P, P, I32, I64, I32, P, P]),
@@ -103,10 +104,32 @@ def call(name: str, *args):
 
 
 _ws_cache = {}
+_ws_scope = ["ws"]
+
+
+class ws_scope:
+    """Workspaces requested inside ``with ws_scope(tag)`` come from a cache private to ``tag``: a captured HIP graph keeps the
+    ADDRESSES of its workspaces, so they must never be regrown or shared with eager callers."""
+
+    def __init__(self, tag: str):
+        self.tag = tag
+
+    def __enter__(self):
+        _ws_scope.append(self.tag)
+
+    def __exit__(self, *exc):
+        _ws_scope.pop()
+
+
+def drop_scope(tag: str):
+    for k in [k for k in _ws_cache if k[2] == tag]:
+        del _ws_cache[k]
 
 
 def workspace(nbytes: int, device, tag: str = "ws") -> torch.Tensor:
     """A per-(device, stream, tag) scratch tensor that only grows (stream-ordered reuse is safe within one stream)."""
+    if tag == "ws":
+        tag = _ws_scope[-1]
     key = (str(device), torch.cuda.current_stream(device).cuda_stream, tag)
     t = _ws_cache.get(key)
     if t is None or t.numel() < nbytes:

@@ -12,12 +12,28 @@
 
 namespace {
 
+// Row-chunk sizes of the backward-weight kernels.  They are functions of the TRUE number of rows (group_row_off[G], read on the
+// device), never of the launch bound, so a launch over a bound (HIP-graph replay) sums in exactly the order of an exact launch.
+//   Cin = 3  : cheap chunks, aim for ~1024 of them, at least 64 rows each
+//   Cin = 128: about 256 row chunks per launch, at least 512 rows each; both multiples of 32
+__host__ __device__ __forceinline__ int chunk3(int M) {
+    int ch = (((M > 0 ? M : 1) + 1023) / 1024 + 31) / 32 * 32;
+    return ch < 64 ? 64 : ch;
+}
+__host__ __device__ __forceinline__ int chunk128(int M) {
+    int ch = (((M > 0 ? M : 1) + 255) / 256 + 31) / 32 * 32;
+    return ch < 512 ? 512 : ch;
+}
+// slots needed for ANY row count <= bound: the chunk size is smallest (64 / 512) when there are few rows
+inline int64_t max_slots3(int64_t bound, int G) { return ceil_div64(bound, 64) < 1024 + G ? ceil_div64(bound, 64) + G : 1024 + G; }
+inline int64_t max_slots128(int64_t bound, int G) { return ceil_div64(bound, 512) < 256 + G ? ceil_div64(bound, 512) + G : 256 + G; }
+
 // ---------------------------------------------------------------------------------------------
 // Cin = Cout = 128 forward / backward-data
 // ---------------------------------------------------------------------------------------------
 template <int TM, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256) void k_conv128(const float* __restrict__ X, const float* __restrict__ W, const int* __restrict__ nbr, int64_t ld,
-                                                 int K, int M_out, int mirror, float* __restrict__ Y) {
+                                                 int K, int M_bound, const int* __restrict__ m_dev, int mirror, float* __restrict__ Y) {
     constexpr int BK = 32, LDA4 = 9 /* (BK+4)/4 float4 per A row: +16 B pad keeps ds_read_b128 conflict-free */;
     constexpr int WM = TM / WAVES_M, WN = 128 / WAVES_N, MT = WM / 32, NT = WN / 32;
     static_assert(WAVES_M * WAVES_N == 4 && MT >= 1 && NT >= 1, "4 waves");
@@ -30,6 +46,8 @@ __global__ __launch_bounds__(256) void k_conv128(const float* __restrict__ X, co
     const int i32 = lane & 31, h = lane >> 5;
     const int wrow0 = (wid / WAVES_N) * WM, wcol0 = (wid % WAVES_N) * WN;
     const int64_t row0 = (int64_t)blockIdx.x * TM;
+    const int M_out = m_dev ? min(*m_dev, M_bound) : M_bound;  // launched over the bound, the true row count lives on the device
+    if (row0 >= M_out) return;
 
     if (tid == 0) s_kmask = 0;
     __syncthreads();
@@ -148,7 +166,7 @@ __global__ __launch_bounds__(256) void k_conv128(const float* __restrict__ X, co
 // Cin = Cout = 128 backward-weight: one workgroup per (row chunk, offset k) -> partial slab [128][128]
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_conv128_bww(const float* __restrict__ X, const float* __restrict__ dY, const int* __restrict__ nbr, int64_t ld,
-                                                     int K, const int* __restrict__ group_row_off, int G, int CH, float* __restrict__ slabs,
+                                                     int K, const int* __restrict__ group_row_off, int G, float* __restrict__ slabs,
                                                      int* __restrict__ slab_valid) {
     // The (in,out) pairs of offset k inside the chunk are first COMPACTED (stable ballot scan, 1024 rows per window), so the matrix
     // cores only see rows that have a neighbour; the contraction then runs over 32 pairs at a time.
@@ -160,6 +178,7 @@ __global__ __launch_bounds__(256) void k_conv128_bww(const float* __restrict__ X
     const int wm0 = (wid >> 1) * 64, wn0 = (wid & 1) * 64;
     const int c = blockIdx.x, k = blockIdx.y;
     int g, r0, r1;
+    const int CH = chunk128(group_row_off[G]);
     if (!resolve_chunk(c, group_row_off, G, CH, &g, &r0, &r1)) return;
     const int* nk = nbr + (int64_t)k * ld;
 
@@ -246,11 +265,12 @@ __global__ __launch_bounds__(256) void k_conv128_bww(const float* __restrict__ X
 }
 
 // dW[g][k][e] = sum over the valid slabs of group g, in slot order (deterministic)
-__global__ void k_slab_reduce(const f32x4* __restrict__ slabs, const int* __restrict__ slab_valid, const int* __restrict__ group_row_off, int G, int CH,
+__global__ void k_slab_reduce(const f32x4* __restrict__ slabs, const int* __restrict__ slab_valid, const int* __restrict__ group_row_off, int G, int cin3,
                               int K, int elems4, f32x4* __restrict__ dW) {
     int e = blockIdx.x * 256 + threadIdx.x;
     int k = blockIdx.y, g = blockIdx.z;
     if (e >= elems4) return;
+    const int CH = cin3 ? chunk3(group_row_off[G]) : chunk128(group_row_off[G]);
     int first = 0;
     for (int j = 0; j < g; ++j) first += (group_row_off[j + 1] - group_row_off[j] + CH - 1) / CH;
     int n = (group_row_off[g + 1] - group_row_off[g] + CH - 1) / CH;
@@ -264,9 +284,11 @@ __global__ void k_slab_reduce(const f32x4* __restrict__ slabs, const int* __rest
 // Cin = 3, Cout = 128 (first layer): bandwidth kernels on the VALU
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_conv3_fwd(const float* __restrict__ X, const float* __restrict__ W /*[K][3][128]*/, const int* __restrict__ nbr,
-                                                   int64_t ld, int K, int M_out, int rows_per_block, float* __restrict__ Y) {
+                                                   int64_t ld, int K, int M_bound, const int* __restrict__ m_dev, int rows_per_block, float* __restrict__ Y) {
     __shared__ f32x4 Ws4[27 * 3 * 32];
     const int tid = threadIdx.x;
+    const int M_out = m_dev ? min(*m_dev, M_bound) : M_bound;
+    if ((int64_t)blockIdx.x * rows_per_block >= M_out) return;
     const f32x4* W4 = (const f32x4*)W;
     for (int i = tid; i < K * 3 * 32; i += 256) Ws4[i] = W4[i];
     __syncthreads();
@@ -294,9 +316,11 @@ __global__ __launch_bounds__(256) void k_conv3_fwd(const float* __restrict__ X, 
 
 // dX[i][ci] = sum_k sum_co dY[nbr[K-1-k][i]][co] * W[k][ci][co]
 __global__ __launch_bounds__(256) void k_conv3_bwd_data(const float* __restrict__ dY, const float* __restrict__ W, const int* __restrict__ nbr, int64_t ld,
-                                                        int K, int M, int rows_per_block, float* __restrict__ dX) {
+                                                        int K, int M_bound, const int* __restrict__ m_dev, int rows_per_block, float* __restrict__ dX) {
     __shared__ f32x4 Ws4[27 * 3 * 32];
     const int tid = threadIdx.x;
+    const int M = m_dev ? min(*m_dev, M_bound) : M_bound;
+    if ((int64_t)blockIdx.x * rows_per_block >= M) return;
     const f32x4* W4 = (const f32x4*)W;
     for (int i = tid; i < K * 3 * 32; i += 256) Ws4[i] = W4[i];
     __syncthreads();
@@ -335,7 +359,7 @@ __global__ __launch_bounds__(256) void k_conv3_bwd_data(const float* __restrict_
 // dW[g][k][ci][co] partial per row chunk on the fp32 matrix cores: out[81 (pad 96)][128] = A^T . dY with the im2col tile
 // A[o][k*3+ci] = X[nbr[k][o]][ci] built in LDS (32 rows at a time).  Wave w owns output columns [32w, 32w+32) and all 3 row tiles.
 __global__ __launch_bounds__(256) void k_conv3_bww(const float* __restrict__ X, const float* __restrict__ dY, const int* __restrict__ nbr, int64_t ld,
-                                                   const int* __restrict__ group_row_off, int G, int CH, float* __restrict__ slabs, int* __restrict__ slab_valid) {
+                                                   const int* __restrict__ group_row_off, int G, float* __restrict__ slabs, int* __restrict__ slab_valid) {
     constexpr int LDA = 97;  // 96 + 1: the im2col writes walk rows (stride LDA) and must not land on one bank
     __shared__ float As[32 * LDA];
     __shared__ f32x4 Ds4[32 * 32];
@@ -343,6 +367,7 @@ __global__ __launch_bounds__(256) void k_conv3_bww(const float* __restrict__ X, 
     const int i32 = lane & 31, h = lane >> 5;
     const int c = blockIdx.x;
     int g, r0, r1;
+    const int CH = chunk3(group_row_off[G]);
     if (!resolve_chunk(c, group_row_off, G, CH, &g, &r0, &r1)) return;
     for (int i = tid; i < 32 * LDA; i += 256) As[i] = 0.f;  // pad columns 81..96 stay zero
     f32x16 acc[3];
@@ -420,33 +445,19 @@ __global__ void k_transpose_kernel(const float* __restrict__ W, int K, int Cin, 
     }
 }
 
-int pick_chunk3(int64_t M) {
-    // Cin = 3: cheap chunks, aim for ~1024 of them, at least 64 rows each
-    int64_t ch = align_up64(ceil_div64(M > 0 ? M : 1, 1024), 32);
-    if (ch < 64) ch = 64;
-    return (int)ch;
-}
-
-int pick_chunk(int64_t M) {
-    // about 256 row chunks per launch, at least 512 rows each, a multiple of 32
-    int64_t ch = align_up64(ceil_div64(M > 0 ? M : 1, 256), 32);
-    if (ch < 512) ch = 512;
-    return (int)ch;
-}
-
 }  // namespace
 
 DD3D_API int64_t dd3d_conv_bwd_weight_ws_bytes(int64_t M_out, int G, int K, int Cin, int Cout) {
-    int CH = Cin == 3 ? pick_chunk3(M_out) : pick_chunk(M_out);
-    int64_t slots = ceil_div64(M_out, CH) + G;
+    int64_t slots = Cin == 3 ? max_slots3(M_out, G) : max_slots128(M_out, G);
     int64_t nslab = (Cin == 3) ? slots : slots * K;
     int64_t per = (Cin == 3) ? (int64_t)K * 3 * Cout : (int64_t)Cin * Cout;
     return align_up64(nslab * per * 4, 256) + align_up64(nslab * 4, 256);
 }
 
 // Y[M_out,Cout] = sum_k X[nbr[k'][o]] . Wmat[k],  k' = mirror ? K-1-k : k.   Wmat is [K,Cin,Cout] row-major.
+// m_dev (nullable): device-side row count; the launch then covers the bound M_out and rows >= *m_dev are not touched.
 DD3D_API int dd3d_conv_fwd(const float* X, int64_t M_in, int Cin, const float* W, int Cout, const int32_t* nbr, int64_t ld, int K, int64_t M_out,
-                           int mirror, float* Y, void* stream) {
+                           const int32_t* m_dev, int mirror, float* Y, void* stream) {
     if (M_out < 0 || M_in < 0 || K != 27 || ld < M_out || Cout != 128 || (Cin != 3 && Cin != 128)) return DD3D_EARG;
     if (M_out >= (1ll << 31) / 128 * 16) return DD3D_ESIZE;
     if (M_out == 0) return 0;
@@ -455,37 +466,38 @@ DD3D_API int dd3d_conv_fwd(const float* X, int64_t M_in, int Cin, const float* W
     if (Cin == 3) {
         if (mirror) return DD3D_EARG;
         const int rpb = 64;
-        k_conv3_fwd<<<dim3((unsigned)ceil_div64(M_out, rpb)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, rpb, Y);
+        k_conv3_fwd<<<dim3((unsigned)ceil_div64(M_out, rpb)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, rpb, Y);
     } else if (M_out >= 128 * 512) {
-        k_conv128<128, 2, 2><<<dim3((unsigned)ceil_div64(M_out, 128)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, mirror, Y);
+        k_conv128<128, 2, 2><<<dim3((unsigned)ceil_div64(M_out, 128)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y);
     } else {
-        k_conv128<64, 1, 4><<<dim3((unsigned)ceil_div64(M_out, 64)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, mirror, Y);
+        k_conv128<64, 1, 4><<<dim3((unsigned)ceil_div64(M_out, 64)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y);
     }
     DD3D_CHECK_LAUNCH();
     return 0;
 }
 
 // dX[M,Cin] for a stride-1 convolution.  Cin==128: pass Wt = transposed kernel [K,Cout,Cin] (dd3d_transpose_kernel); Cin==3: pass W itself.
-DD3D_API int dd3d_conv_bwd_data(const float* dY, int64_t M, int Cout, const float* W_or_Wt, int Cin, const int32_t* nbr, int64_t ld, int K, float* dX,
-                                void* stream) {
-    if (Cin == 128) return dd3d_conv_fwd(dY, M, Cout, W_or_Wt, Cin, nbr, ld, K, M, 1, dX, stream);
+DD3D_API int dd3d_conv_bwd_data(const float* dY, int64_t M, const int32_t* m_dev, int Cout, const float* W_or_Wt, int Cin, const int32_t* nbr, int64_t ld,
+                                int K, float* dX, void* stream) {
+    if (Cin == 128) return dd3d_conv_fwd(dY, M, Cout, W_or_Wt, Cin, nbr, ld, K, M, m_dev, 1, dX, stream);
     if (M < 0 || K != 27 || ld < M || Cout != 128 || Cin != 3) return DD3D_EARG;
     if (M == 0) return 0;
     if (!dY || !W_or_Wt || !nbr || !dX) return DD3D_EARG;
     const int rpb = 64;
-    k_conv3_bwd_data<<<dim3((unsigned)ceil_div64(M, rpb)), 256, 0, (hipStream_t)stream>>>(dY, W_or_Wt, nbr, ld, K, (int)M, rpb, dX);
+    k_conv3_bwd_data<<<dim3((unsigned)ceil_div64(M, rpb)), 256, 0, (hipStream_t)stream>>>(dY, W_or_Wt, nbr, ld, K, (int)M, m_dev, rpb, dX);
     DD3D_CHECK_LAUNCH();
     return 0;
 }
 
-// dW[G,K,Cin,Cout]; rows of group g are [group_row_off[g], group_row_off[g+1]) (device array, G+1 ints)
+// dW[G,K,Cin,Cout]; rows of group g are [group_row_off[g], group_row_off[g+1]) (device array, G+1 ints).  M_out may be a bound
+// (>= group_row_off[G]): the row chunking follows the true row count, read on the device.
 DD3D_API int dd3d_conv_bwd_weight(const float* X, int Cin, const float* dY, int Cout, const int32_t* nbr, int64_t ld, int K, int64_t M_out,
                                   const int32_t* group_row_off, int G, float* dW, void* ws, int64_t ws_bytes, void* stream) {
     if (M_out < 0 || K != 27 || ld < M_out || Cout != 128 || (Cin != 3 && Cin != 128) || G <= 0 || !group_row_off || !dW) return DD3D_EARG;
+    if (M_out >= (1ll << 31) / 128) return DD3D_ESIZE;
     if (ws_bytes < dd3d_conv_bwd_weight_ws_bytes(M_out, G, K, Cin, Cout) || !ws) return DD3D_EWS;
     hipStream_t st = (hipStream_t)stream;
-    int CH = Cin == 3 ? pick_chunk3(M_out) : pick_chunk(M_out);
-    int64_t slots = ceil_div64(M_out, CH) + G;
+    int64_t slots = Cin == 3 ? max_slots3(M_out, G) : max_slots128(M_out, G);
     int64_t nslab = (Cin == 3) ? slots : slots * K;
     int64_t per = (Cin == 3) ? (int64_t)K * 3 * Cout : (int64_t)Cin * Cout;
     float* slabs = (float*)ws;
@@ -494,15 +506,15 @@ DD3D_API int dd3d_conv_bwd_weight(const float* X, int Cin, const float* dY, int 
     if (M_out > 0) {
         if (!X || !dY || !nbr) return DD3D_EARG;
         if (Cin == 3)
-            k_conv3_bww<<<dim3((unsigned)slots), 256, 0, st>>>(X, dY, nbr, ld, group_row_off, G, CH, slabs, valid);
+            k_conv3_bww<<<dim3((unsigned)slots), 256, 0, st>>>(X, dY, nbr, ld, group_row_off, G, slabs, valid);
         else
-            k_conv128_bww<<<dim3((unsigned)slots, K), 256, 0, st>>>(X, dY, nbr, ld, K, group_row_off, G, CH, slabs, valid);
+            k_conv128_bww<<<dim3((unsigned)slots, K), 256, 0, st>>>(X, dY, nbr, ld, K, group_row_off, G, slabs, valid);
     }
     if (Cin == 3)
-        k_slab_reduce<<<dim3((unsigned)ceil_div64(per / 4, 256), 1, G), 256, 0, st>>>((const f32x4*)slabs, valid, group_row_off, G, CH, 1, (int)(per / 4),
+        k_slab_reduce<<<dim3((unsigned)ceil_div64(per / 4, 256), 1, G), 256, 0, st>>>((const f32x4*)slabs, valid, group_row_off, G, 1, 1, (int)(per / 4),
                                                                                      (f32x4*)dW);
     else
-        k_slab_reduce<<<dim3((unsigned)ceil_div64(per / 4, 256), K, G), 256, 0, st>>>((const f32x4*)slabs, valid, group_row_off, G, CH, K, (int)(per / 4),
+        k_slab_reduce<<<dim3((unsigned)ceil_div64(per / 4, 256), K, G), 256, 0, st>>>((const f32x4*)slabs, valid, group_row_off, G, 0, K, (int)(per / 4),
                                                                                      (f32x4*)dW);
     DD3D_CHECK_LAUNCH();
     return 0;

@@ -317,6 +317,71 @@ __global__ void k_dense_sites(const int4* __restrict__ C, const int* m_dev, int6
     if (vox_at) vox_at[(int64_t)s * B + c.x] = (int)r;
 }
 
+// ---- real-batch assembly on the device ------------------------------------------------------
+// pt_off[b] = sum_{b' < b} min(points of cloud ids[b'], cap): ONE block scans the B sampled clouds; total -> *n_dev
+__global__ void k_cloud_offsets(const int* __restrict__ pool_off, const int* __restrict__ ids, int B, int n_pool, int cap, int64_t bound,
+                                int* __restrict__ pt_off, int* __restrict__ n_dev, int* err) {
+    __shared__ int s_w[16];
+    __shared__ int s_carry;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < B; base += 1024) {
+        int b = base + threadIdx.x;
+        int v = 0;
+        if (b < B) {
+            int id = ids[b];
+            if (id < 0 || id >= n_pool) atomicOr(err, 4);  // sampled index outside the pool: the cloud comes out empty
+            else v = min(pool_off[id + 1] - pool_off[id], cap);
+        }
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) s_w[w] = incl;
+        __syncthreads();
+        int wbase = 0, tot = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            int x = s_w[j];
+            if (j < w) wbase += x;
+            tot += x;
+        }
+        int carry = s_carry;
+        if (b < B) pt_off[b] = carry + wbase + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int total = s_carry;
+        if (total > bound) {
+            atomicOr(err, 4);  // the caller's bound is too small: rows beyond it are dropped
+            total = (int)bound;
+        }
+        pt_off[B] = total;
+        *n_dev = total;
+    }
+}
+
+// one workgroup per sampled cloud: rows (b, p0, p1, p2) into coords and (p0, p1, p2) into feats, in pool order
+__global__ void k_gather_clouds(const float* __restrict__ pool_xyz, const int* __restrict__ pool_off, const int* __restrict__ ids, int n_pool,
+                                const int* __restrict__ pt_off, int B, float4* __restrict__ coords, float* __restrict__ feats) {
+    const int b = blockIdx.x;
+    const int id = ids[b];
+    if (id < 0 || id >= n_pool) return;
+    const int dst0 = pt_off[b], n = min(pt_off[b + 1], pt_off[B]) - dst0;
+    const float* src = pool_xyz + (int64_t)pool_off[id] * 3;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        float x = src[i * 3 + 0], y = src[i * 3 + 1], z = src[i * 3 + 2];
+        coords[dst0 + i] = make_float4((float)b, x, y, z);
+        float* f = feats + (int64_t)(dst0 + i) * 3;
+        f[0] = x; f[1] = y; f[2] = z;
+    }
+}
+
 inline dim3 grid1(int64_t n) { return dim3((unsigned)ceil_div64(n > 0 ? n : 1, TB)); }
 
 int large_exclusive_scan(const int* in, int64_t n, int* out, int* bsum /*[ceil(n/1024)]*/, hipStream_t st) {
@@ -335,7 +400,7 @@ int large_exclusive_scan(const int* in, int64_t n, int* out, int* bsum /*[ceil(n
 // C ABI
 // =============================================================================================
 
-DD3D_API int dd3d_version() { return 100; }
+DD3D_API int dd3d_version() { return 101; }
 
 DD3D_API int64_t dd3d_table_capacity(int64_t n) {
     int64_t cap = 1024;
@@ -489,6 +554,20 @@ DD3D_API int dd3d_dense_sites(const int32_t* C, const int32_t* m_dev, int64_t bo
     if (!C || !site) return DD3D_EARG;
     k_min_coord<<<grid1(bound), TB, 0, st>>>((const int4*)C, m_dev, bound, cloud_group, gmin);
     k_dense_sites<<<grid1(bound), TB, 0, st>>>((const int4*)C, m_dev, bound, cloud_group, gmin, tensor_stride, E0, E1, E2, B, site, vox_at, err_dev);
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}
+
+// Collated real batch from a resident point pool: cloud b of the batch = pool cloud ids[b], first `cap` points, batch index b.
+// coords[bound,4] / feats[bound,3] (first *n_dev rows valid), pt_off[B+1].  *err_dev |= 4 if an id is outside the pool or the
+// points do not fit into `bound`.
+DD3D_API int dd3d_gather_clouds(const float* pool_xyz, const int32_t* pool_off, int n_pool, const int32_t* ids, int B, int cap, int64_t bound,
+                                float* coords, float* feats, int32_t* pt_off, int32_t* n_dev, int32_t* err_dev, void* stream) {
+    if (B < 0 || n_pool < 0 || cap < 0 || bound < 0 || bound >= (1ll << 31) || !pt_off || !n_dev || !err_dev) return DD3D_EARG;
+    if (B > 0 && (!pool_xyz || !pool_off || !ids || !coords || !feats)) return DD3D_EARG;
+    hipStream_t st = (hipStream_t)stream;
+    k_cloud_offsets<<<1, 1024, 0, st>>>(pool_off, ids, B, n_pool, cap, bound, pt_off, n_dev, err_dev);
+    if (B > 0) k_gather_clouds<<<dim3(B), 128, 0, st>>>(pool_xyz, pool_off, ids, n_pool, pt_off, B, (float4*)coords, feats);
     DD3D_CHECK_LAUNCH();
     return 0;
 }

@@ -5,10 +5,19 @@
 
 namespace {
 
+// Row-chunk size of the pooling backward: a function of the TRUE row count (group_row_off[G], read on the device), not of the launch
+// bound, so a launch over a bound sums in the same order as an exact launch.  About 1024 chunks, at least 64 rows, a multiple of 8.
+__host__ __device__ __forceinline__ int arp_chunk(int M) {
+    int ch = (((M > 0 ? M : 1) + 1023) / 1024 + 7) / 8 * 8;
+    return ch < 64 ? 64 : ch;
+}
+inline int64_t arp_max_slots(int64_t bound, int G) { return (ceil_div64(bound, 64) < 1024 ? ceil_div64(bound, 64) : 1024) + G; }
+
 // ---- voxel mean -----------------------------------------------------------------------------
-__global__ void k_voxel_mean_fwd(const float* __restrict__ feats, int C, const int* __restrict__ vox_off, const int* __restrict__ vox_pts, int64_t M,
-                                 float* __restrict__ F0) {
+__global__ void k_voxel_mean_fwd(const float* __restrict__ feats, int C, const int* __restrict__ vox_off, const int* __restrict__ vox_pts, int64_t M_bound,
+                                 const int* __restrict__ m_dev, float* __restrict__ F0) {
     int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t M = m_dev ? min((int64_t)*m_dev, M_bound) : M_bound;
     if (t >= M * C) return;
     int64_t v = t / C;
     int c = (int)(t - v * C);
@@ -104,10 +113,11 @@ __global__ __launch_bounds__(256) void k_inorm_bwd(const f32x4* __restrict__ g, 
 // ---- fused affine + ReLU + max-pool (k=2, s=2) ------------------------------------------------
 // out[o][c] = max over existing children i of relu(xhat[i][c]*w[c]+b[c]); first maximum in offset order wins; arg = child row
 __global__ __launch_bounds__(256) void k_arp_fwd(const f32x4* __restrict__ xhat, const f32x4* __restrict__ w, const f32x4* __restrict__ bias,
-                                                 int use_affine_relu, const int* __restrict__ kids, int64_t ld, int Kp, int64_t M_out,
-                                                 f32x4* __restrict__ out, int4* __restrict__ arg) {
+                                                 int use_affine_relu, const int* __restrict__ kids, int64_t ld, int Kp, int64_t M_bound,
+                                                 const int* __restrict__ m_dev, f32x4* __restrict__ out, int4* __restrict__ arg) {
     const int c4 = threadIdx.x & 31;
     int64_t o = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int64_t M_out = m_dev ? min((int64_t)*m_dev, M_bound) : M_bound;
     if (o >= M_out) return;
     f32x4 ww = {1.f, 1.f, 1.f, 1.f}, bb = {0.f, 0.f, 0.f, 0.f};
     if (use_affine_relu) {
@@ -141,14 +151,14 @@ __global__ __launch_bounds__(256) void k_arp_fwd(const f32x4* __restrict__ xhat,
 //   g_xhat += ga_prev * gw_extra[group]   (second-order term of the matching loss through the affine weight gradient)
 __global__ __launch_bounds__(256) void k_arp_bwd(const f32x4* __restrict__ g_pool, const int4* __restrict__ arg, const int* __restrict__ parent,
                                                  const f32x4* __restrict__ xhat, const f32x4* __restrict__ w, const f32x4* __restrict__ bias,
-                                                 int use_affine_relu, const int* __restrict__ group_row_off, int G, int CH,
+                                                 int use_affine_relu, const int* __restrict__ group_row_off, int G,
                                                  f32x4* __restrict__ g_xhat, f32x4* __restrict__ ga_out, const f32x4* __restrict__ ga_prev,
                                                  const f32x4* __restrict__ gw_extra, f32x4* __restrict__ partial /*[slots][2][32]*/,
                                                  int* __restrict__ slab_valid) {
     __shared__ f32x4 s_red[256];
     const int c4 = threadIdx.x & 31, rl = threadIdx.x >> 5;
     int g, r0, r1;
-    if (!resolve_chunk(blockIdx.x, group_row_off, G, CH, &g, &r0, &r1)) return;
+    if (!resolve_chunk(blockIdx.x, group_row_off, G, arp_chunk(group_row_off[G]), &g, &r0, &r1)) return;
     f32x4 ww = {1.f, 1.f, 1.f, 1.f}, bb = {0.f, 0.f, 0.f, 0.f};
     if (use_affine_relu) {
         ww = w[c4];
@@ -191,9 +201,10 @@ __global__ __launch_bounds__(256) void k_arp_bwd(const f32x4* __restrict__ g_poo
 
 // out[g][j][c4] = sum over the chunk slots of group g (every slot of a group is written by k_arp_bwd); 4 slot-lanes per output sum
 // slots s = lane, lane+4, ... in order and are then combined in lane order: deterministic.  j in {0: d weight, 1: d bias}
-__global__ __launch_bounds__(256) void k_arp_reduce(const f32x4* __restrict__ partial, const int* __restrict__ group_row_off, int G, int CH,
+__global__ __launch_bounds__(256) void k_arp_reduce(const f32x4* __restrict__ partial, const int* __restrict__ group_row_off, int G,
                                                     f32x4* __restrict__ gw_w, f32x4* __restrict__ gw_b) {
     __shared__ f32x4 s_red[256];
+    const int CH = arp_chunk(group_row_off[G]);
     const int g = blockIdx.x, c4 = threadIdx.x & 31, j = (threadIdx.x >> 5) & 1, sl = threadIdx.x >> 6;
     int first = 0;
     for (int q = 0; q < g; ++q) first += (group_row_off[q + 1] - group_row_off[q] + CH - 1) / CH;
@@ -220,20 +231,14 @@ __global__ void k_scale_rows_by_group(const f32x4* __restrict__ ga, const f32x4*
     out[i * 32 + c4] = ga[i * 32 + c4] * gw[(int64_t)g * 32 + c4];
 }
 
-int arp_chunk(int64_t M) {
-    int64_t ch = align_up64(ceil_div64(M > 0 ? M : 1, 1024), 8);
-    if (ch < 64) ch = 64;
-    return (int)ch;
-}
-
 }  // namespace
 
-DD3D_API int dd3d_voxel_mean_fwd(const float* feats, int64_t N, int C, const int32_t* vox_off, const int32_t* vox_pts, int64_t M, float* F0,
-                                 void* stream) {
+DD3D_API int dd3d_voxel_mean_fwd(const float* feats, int64_t N, int C, const int32_t* vox_off, const int32_t* vox_pts, int64_t M, const int32_t* m_dev,
+                                 float* F0, void* stream) {
     if (N < 0 || M < 0 || C <= 0) return DD3D_EARG;
     if (M == 0) return 0;
     if (!feats || !vox_off || !vox_pts || !F0) return DD3D_EARG;
-    k_voxel_mean_fwd<<<dim3((unsigned)ceil_div64(M * C, 256)), 256, 0, (hipStream_t)stream>>>(feats, C, vox_off, vox_pts, M, F0);
+    k_voxel_mean_fwd<<<dim3((unsigned)ceil_div64(M * C, 256)), 256, 0, (hipStream_t)stream>>>(feats, C, vox_off, vox_pts, M, m_dev, F0);
     DD3D_CHECK_LAUNCH();
     return 0;
 }
@@ -268,18 +273,18 @@ DD3D_API int dd3d_inorm_bwd(const float* g, const float* xhat, const float* inv_
 
 // out[M_out,128], arg[M_out,128] (child row that won).  w/b may be null with use_affine_relu = 0 (plain max-pool).
 DD3D_API int dd3d_affine_relu_pool_fwd(const float* xhat, const float* w, const float* b, int use_affine_relu, int C, const int32_t* kids, int64_t ld,
-                                       int Kp, int64_t M_out, float* out, int32_t* arg, void* stream) {
+                                       int Kp, int64_t M_out, const int32_t* m_dev, float* out, int32_t* arg, void* stream) {
     if (M_out < 0 || C != 128 || Kp <= 0 || ld < M_out || (use_affine_relu && (!w || !b))) return DD3D_EARG;
     if (M_out == 0) return 0;
     if (!xhat || !kids || !out || !arg) return DD3D_EARG;
     k_arp_fwd<<<dim3((unsigned)ceil_div64(M_out, 8)), 256, 0, (hipStream_t)stream>>>((const f32x4*)xhat, (const f32x4*)w, (const f32x4*)b, use_affine_relu,
-                                                                                    kids, ld, Kp, M_out, (f32x4*)out, (int4*)arg);
+                                                                                    kids, ld, Kp, M_out, m_dev, (f32x4*)out, (int4*)arg);
     DD3D_CHECK_LAUNCH();
     return 0;
 }
 
 DD3D_API int64_t dd3d_arp_bwd_ws_bytes(int64_t M_in, int G) {
-    int64_t slots = ceil_div64(M_in, arp_chunk(M_in)) + G;
+    int64_t slots = arp_max_slots(M_in, G);
     return align_up64(slots * 2 * 128 * 4, 256) + align_up64(slots * 4, 256);
 }
 
@@ -293,18 +298,17 @@ DD3D_API int dd3d_affine_relu_pool_bwd(const float* g_pool, const int32_t* arg, 
         return DD3D_EARG;
     if (ws_bytes < dd3d_arp_bwd_ws_bytes(M_in, G) || !ws) return DD3D_EWS;
     hipStream_t st = (hipStream_t)stream;
-    int CH = arp_chunk(M_in);
-    int64_t slots = ceil_div64(M_in, CH) + G;
+    int64_t slots = arp_max_slots(M_in, G);
     f32x4* partial = (f32x4*)ws;
     int* valid = (int*)((char*)ws + align_up64(slots * 2 * 128 * 4, 256));
     DD3D_HIP(hipMemsetAsync(valid, 0, slots * 4, st));
     if (M_in > 0) {
         if (!g_pool || !arg || !parent || !xhat || !g_xhat) return DD3D_EARG;
         k_arp_bwd<<<dim3((unsigned)slots), 256, 0, st>>>((const f32x4*)g_pool, (const int4*)arg, parent, (const f32x4*)xhat, (const f32x4*)w,
-                                                         (const f32x4*)b, use_affine_relu, group_row_off, G, CH, (f32x4*)g_xhat, (f32x4*)ga_out,
+                                                         (const f32x4*)b, use_affine_relu, group_row_off, G, (f32x4*)g_xhat, (f32x4*)ga_out,
                                                          (const f32x4*)ga_prev, (const f32x4*)gw_extra, gw_w ? partial : nullptr, valid);
     }
-    if (gw_w) k_arp_reduce<<<dim3(G), 256, 0, st>>>(partial, group_row_off, G, CH, (f32x4*)gw_w, (f32x4*)gw_b);
+    if (gw_w) k_arp_reduce<<<dim3(G), 256, 0, st>>>(partial, group_row_off, G, (f32x4*)gw_w, (f32x4*)gw_b);
     DD3D_CHECK_LAUNCH();
     return 0;
 }

@@ -38,12 +38,15 @@ def _empty(shape, dev, dtype=_F32):
 class _Pass:
     """Forward + first-order backward of MEConvExp over one class-batched set of clouds; keeps what the second-order pass needs."""
 
-    def __init__(self, net, coords, B, G, cloud_group, group_cloud_off):
-        """Phase 1 (no host sync): every coordinate map of the pass, enqueued on the current stream."""
+    def __init__(self, net, coords, B, G, cloud_group, group_cloud_off, n_dev=None, static=False):
+        """Phase 1 (no host sync): every coordinate map of the pass, enqueued on the current stream.
+        ``static``: never read a size back -- every launch covers its bound and takes the true row count from the device
+        (``n_dev`` = number of valid rows of ``coords``), so the pass can be captured into a HIP graph."""
         dev = coords.device
         self.dev, self.B, self.G, self.net = dev, B, G, net
         self.cloud_group, self.gco = cloud_group, group_cloud_off
-        cm = self.cm = CoordinateManager(coords, B)
+        self.static = static
+        cm = self.cm = CoordinateManager(coords, B, n_dev=n_dev)
         self.N = cm.N
         k0, p0 = cm.kernel_map(1, 1, 3), cm.kernel_map(1, 2, 2)
         k1, p1 = cm.kernel_map(2, 2, 3), cm.kernel_map(2, 4, 2)
@@ -59,9 +62,14 @@ class _Pass:
         cloud_group, group_cloud_off = self.cloud_group, self.gco
         (k0, ld0), (p0, pl0), (k1, ld1), (p1, pl1), seg1, seg2, gro1, gro2 = self._pre
         st = L.stream()
-        cm.sync()
-        M0, M1, M2 = cm.num_rows(1), cm.num_rows(2), cm.num_rows(4)
-        self.M = (M0, M1, M2)
+        if self.static:
+            M0, M1, M2 = cm.rows_bound(1), cm.rows_bound(2), cm.rows_bound(4)
+            c0, c1, c2 = cm.count_ptr(1), cm.count_ptr(2), cm.count_ptr(4)
+        else:
+            cm.sync()
+            M0, M1, M2 = cm.num_rows(1), cm.num_rows(2), cm.num_rows(4)
+            c0 = c1 = c2 = None
+        self.M, self.cnt = (M0, M1, M2), (c0, c1, c2)
         self.maps = (k0, ld0, p0, pl0, k1, ld1, p1, pl1, seg1, seg2, gro1, gro2)
         conv0, in0, conv1, in1 = net.features[0], net.features[1], net.features[4], net.features[5]
         W0, W1 = conv0.kernel.detach(), conv1.kernel.detach()
@@ -80,19 +88,19 @@ class _Pass:
         # ---------------- forward ----------------
         feats = feats.detach().contiguous()
         F0 = self.F0 = _empty((M0, 3), dev)
-        L.call("dd3d_voxel_mean_fwd", L.ptr(feats), self.N, 3, L.ptr(cm.vox_off), L.ptr(cm.vox_pts), M0, L.ptr(F0), st)
+        L.call("dd3d_voxel_mean_fwd", L.ptr(feats), self.N, 3, L.ptr(cm.vox_off), L.ptr(cm.vox_pts), M0, c0, L.ptr(F0), st)
         Y0 = _empty((M0, 128), dev)
-        L.call("dd3d_conv_fwd", L.ptr(F0), M0, 3, L.ptr(W0), 128, L.ptr(k0), ld0, 27, M0, 0, L.ptr(Y0), st)
+        L.call("dd3d_conv_fwd", L.ptr(F0), M0, 3, L.ptr(W0), 128, L.ptr(k0), ld0, 27, M0, c0, 0, L.ptr(Y0), st)
         xh0, is0 = self.xh0, self.is0 = _empty((M0, 128), dev), _empty((B, 128), dev)
         L.call("dd3d_inorm_fwd", L.ptr(Y0), L.ptr(seg1), B, 128, L.ptr(xh0), L.ptr(is0), st)
         P0, arg0 = self.P0, self.arg0 = _empty((M1, 128), dev), _empty((M1, 128), dev, _I32)
-        L.call("dd3d_affine_relu_pool_fwd", L.ptr(xh0), L.ptr(w1), L.ptr(b1), 1, 128, L.ptr(p0), pl0, 8, M1, L.ptr(P0), L.ptr(arg0), st)
+        L.call("dd3d_affine_relu_pool_fwd", L.ptr(xh0), L.ptr(w1), L.ptr(b1), 1, 128, L.ptr(p0), pl0, 8, M1, c1, L.ptr(P0), L.ptr(arg0), st)
         Y1 = _empty((M1, 128), dev)
-        L.call("dd3d_conv_fwd", L.ptr(P0), M1, 128, L.ptr(W1), 128, L.ptr(k1), ld1, 27, M1, 0, L.ptr(Y1), st)
+        L.call("dd3d_conv_fwd", L.ptr(P0), M1, 128, L.ptr(W1), 128, L.ptr(k1), ld1, 27, M1, c1, 0, L.ptr(Y1), st)
         xh1, is1 = self.xh1, self.is1 = _empty((M1, 128), dev), _empty((B, 128), dev)
         L.call("dd3d_inorm_fwd", L.ptr(Y1), L.ptr(seg2), B, 128, L.ptr(xh1), L.ptr(is1), st)
         P1, arg1 = self.P1, self.arg1 = _empty((M2, 128), dev), _empty((M2, 128), dev, _I32)
-        L.call("dd3d_affine_relu_pool_fwd", L.ptr(xh1), L.ptr(w5), L.ptr(b5), 1, 128, L.ptr(p1), pl1, 8, M2, L.ptr(P1), L.ptr(arg1), st)
+        L.call("dd3d_affine_relu_pool_fwd", L.ptr(xh1), L.ptr(w5), L.ptr(b5), 1, 128, L.ptr(p1), pl1, 8, M2, c2, L.ptr(P1), L.ptr(arg1), st)
         logits = self.logits = _empty((B, J), dev)
         L.call("dd3d_sparse_linear_fwd", L.ptr(P1), L.ptr(dp.site), L.ptr(dp.seg_off), B, 128, None, L.ptr(Wsm), sst, J, L.ptr(cls_b),
                L.ptr(logits), st)
@@ -115,7 +123,7 @@ class _Pass:
         L.call("dd3d_inorm_bwd", L.ptr(gx1), L.ptr(xh1), L.ptr(is1), L.ptr(seg2), B, 128, L.ptr(gY1), st)
         g_W1 = self._bww(P0, 128, gY1, k1, ld1, M1, gro2)
         gP0 = _empty((M1, 128), dev)
-        L.call("dd3d_conv_bwd_data", L.ptr(gY1), M1, 128, L.ptr(W1t), 128, L.ptr(k1), ld1, 27, L.ptr(gP0), st)
+        L.call("dd3d_conv_bwd_data", L.ptr(gY1), M1, c1, 128, L.ptr(W1t), 128, L.ptr(k1), ld1, 27, L.ptr(gP0), st)
         gx0, self.ga0, g_w1, g_b1 = self._arp_bwd(gP0, arg0, cm.parent(2), xh0, w1, b1, gro1, M0, keep_ga, True)
         gY0 = _empty((M0, 128), dev)
         L.call("dd3d_inorm_bwd", L.ptr(gx0), L.ptr(xh0), L.ptr(is0), L.ptr(seg1), B, 128, L.ptr(gY0), st)
@@ -171,12 +179,12 @@ class _Pass:
         hY1 = _empty((M1, 128), dev)
         L.call("dd3d_inorm_bwd", L.ptr(hx1), L.ptr(self.xh1), L.ptr(self.is1), L.ptr(seg2), B, 128, L.ptr(hY1), st)
         hP0 = _empty((M1, 128), dev)
-        L.call("dd3d_conv_bwd_data", L.ptr(hY1), M1, 128, L.ptr(self.W1t), 128, L.ptr(k1), ld1, 27, L.ptr(hP0), st)
+        L.call("dd3d_conv_bwd_data", L.ptr(hY1), M1, self.cnt[1], 128, L.ptr(self.W1t), 128, L.ptr(k1), ld1, 27, L.ptr(hP0), st)
         hx0, _, _, _ = self._arp_bwd(hP0, self.arg0, cm.parent(2), self.xh0, w1, b1, gro1, M0, False, False, self.ga0, G_w1)
         hY0 = _empty((M0, 128), dev)
         L.call("dd3d_inorm_bwd", L.ptr(hx0), L.ptr(self.xh0), L.ptr(self.is0), L.ptr(seg1), B, 128, L.ptr(hY0), st)
         hF0 = _empty((M0, 3), dev)
-        L.call("dd3d_conv_bwd_data", L.ptr(hY0), M0, 128, L.ptr(W0), 3, L.ptr(k0), ld0, 27, L.ptr(hF0), st)
+        L.call("dd3d_conv_bwd_data", L.ptr(hY0), M0, self.cnt[0], 128, L.ptr(W0), 3, L.ptr(k0), ld0, 27, L.ptr(hF0), st)
         dfeats = _empty((self.N, 3), dev)
         L.call("dd3d_voxel_mean_bwd", L.ptr(hF0), M0, 3, L.ptr(cm.levels[1].inv), L.ptr(cm.vox_off), self.N, L.ptr(dfeats), st)
         return dfeats
@@ -209,10 +217,17 @@ def grouped_match_loss(gw_syn: List[torch.Tensor], gw_real: List[torch.Tensor], 
 
 
 class FusedDistiller:
-    """Same constructor and state as ``mnist_distill.Distiller`` (MEConvExp only); ``outer_step`` runs the class-batched path."""
+    """Same constructor and state as ``mnist_distill.Distiller`` (MEConvExp only); ``outer_step`` runs the class-batched path.
+
+    ``graph=True`` (default): the whole step -- real-batch assembly from a point pool resident in HBM, both passes, the matching loss,
+    the backward into the synthetic points and the SGD update -- is captured ONCE into a HIP graph and replayed; per step the host
+    draws the sample indices (``np.random.permutation`` per class, as mnist_distill.py:200-203 does), uploads them and launches the
+    graph.  Every launch inside covers a bound and reads the true row counts from device memory, so batches of different sizes
+    replay through the same graph.  ``graph=False``: the same kernels enqueued eagerly with exact sizes (one size read-back per pass).
+    Both modes produce bit-identical results (``tests/test_gpu_fused.py``)."""
 
     def __init__(self, images_all, indices_class, network, ipc, num_classes=10, num_points=250, batch_size=256, dist_opt="modmse",
-                 dist_lr=0.1, device=None, seed=0, image_syn=None, classes=None, momentum=0.5):
+                 dist_lr=0.1, device=None, seed=0, image_syn=None, classes=None, momentum=0.5, graph=True):
         self.device = dev = torch.device(device or "cuda")
         self.images_all = images_all.to(dev)
         self.indices_class = [np.asarray(ix) for ix in indices_class]
@@ -238,17 +253,31 @@ class FusedDistiller:
         # the real and the synthetic pass are independent until the loss: they run on two streams, so the small synthetic kernels and
         # both chains of latency-bound map kernels overlap with the large real-batch kernels
         self.stream_real, self.stream_syn = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-        # next step's real batch is sampled on its own stream while this step's kernels run (it depends on nothing the step computes)
+        # eager mode: next step's real batch is sampled on its own stream while this step's kernels run
         self.stream_data, self._prefetched = torch.cuda.Stream(dev), None
+        self.use_graph = bool(graph) and G > 0
+        self._graph = self._static = None
+        self._scope = "graph%x" % id(self)
+
+    def __del__(self):
+        try:
+            L.drop_scope(self._scope)
+        except Exception:
+            pass
 
     def clamp(self):
         s = self.image_syn
         s.clamp_(0, 27)
         s[:, :, 0] = 0
 
+    # ------------------------------------------------------------------ eager-mode real batch (host-sized tensors)
+    def _draw(self):
+        """mnist_distill.py:200-203 for every owned class: np.random.permutation(indices_class[c])[:batch_size]."""
+        return np.concatenate([self.rng.permutation(self.indices_class[c])[:self.batch_size] for c in self.classes])
+
     def sample_real(self):
         """mnist_distill.py:200-208 for every owned class at once: one gather + one nonzero."""
-        idx = np.concatenate([self.rng.permutation(self.indices_class[c])[:self.batch_size] for c in self.classes])
+        idx = self._draw()
         sizes = [min(self.batch_size, len(self.indices_class[c])) for c in self.classes]
         return self.real_batch_from_images(self.images_all[torch.as_tensor(idx, device=self.device)], sizes)
 
@@ -261,19 +290,62 @@ class FusedDistiller:
         b["max_per"] = int(max(sizes))
         return b
 
-    def outer_step(self, real_batch=None, apply_update=True):
+    # ------------------------------------------------------------------ static (graph) mode: point pool + fixed-address buffers
+    def _build_static(self):
+        """Point pool of the whole image set (CSR, resident in HBM) and the fixed-address buffers of the captured step."""
+        dev, npts = self.device, self.num_points
+        n_img = int(self.images_all.shape[0])
+        off = [torch.zeros(1, dtype=torch.int64, device=dev)]
+        xyz = []
+        total = 0
+        for a in range(0, n_img, 8192):           # chunks keep the one-time nonzero() temporaries small
+            imgs = self.images_all[a:a + 8192]
+            b = batch_from_images(imgs, torch.zeros(imgs.shape[0], dtype=torch.int64, device=dev), npts)
+            cnt = torch.bincount(b["coordinates"][:, 0].long(), minlength=imgs.shape[0])
+            off.append(torch.cumsum(cnt, 0) + total)
+            total += int(cnt.sum().item())
+            xyz.append(b["features"])
+        st = type("Static", (), {})()
+        st.pool_off = torch.cat(off).to(_I32).contiguous()
+        st.pool_xyz = torch.cat(xyz).contiguous() if total else torch.zeros((1, 3), device=dev)
+        st.n_pool = n_img
+        counts = (st.pool_off[1:] - st.pool_off[:-1]).cpu().numpy()
+        sizes = [min(self.batch_size, len(self.indices_class[c])) for c in self.classes]
+        # tight bound on the points of one sampled batch: the `size` largest clouds of every class
+        bound = sum(int(np.sort(counts[self.indices_class[c]])[::-1][:n].sum()) for c, n in zip(self.classes, sizes))
+        st.bound = max(256, (bound + 255) // 256 * 256)
+        st.sizes, st.B = sizes, int(sum(sizes))
+        st.ids = torch.zeros(max(st.B, 1), dtype=_I32, device=dev)
+        st.coords = torch.zeros((st.bound, 4), dtype=_F32, device=dev)
+        st.feats = torch.zeros((st.bound, 3), dtype=_F32, device=dev)
+        st.pt_off = torch.zeros(st.B + 1, dtype=_I32, device=dev)
+        st.n = torch.zeros(1, dtype=_I32, device=dev)
+        st.err = torch.zeros(1, dtype=_I32, device=dev)
+        st.labels = torch.tensor(np.repeat(self.classes, sizes), device=dev, dtype=_I32)
+        st.cloud_group = torch.tensor(np.repeat(np.arange(self.G), sizes), device=dev, dtype=_I32)
+        st.gco = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), device=dev, dtype=_I32)
+        st.max_per = int(max(sizes))
+        st.pin = [torch.empty(max(st.B, 1), dtype=_I32).pin_memory() for _ in range(4)]
+        st.pin_ev = [torch.cuda.Event() for _ in range(4)]
+        st.pin_i = 0
+        self._static = st
+
+    def _upload_ids(self):
+        """Host side of a graph step: draw the sample, stage it in pinned memory, enqueue the (tiny) upload."""
+        st = self._static
+        i = st.pin_i
+        st.pin_i = (i + 1) % len(st.pin)
+        st.pin_ev[i].synchronize()                # the upload that last used this staging buffer has finished
+        st.pin[i].numpy()[:st.B] = self._draw()
+        st.ids.copy_(st.pin[i], non_blocking=True)
+        st.pin_ev[i].record()
+
+    # ------------------------------------------------------------------ the step
+    def _compute(self, rb, static):
+        """Everything after the real batch exists: both passes, matching loss, backward into the points, SGD update."""
         dev, G, ipc, npts = self.device, self.G, self.ipc, self.num_points
-        self.clamp()
         main = torch.cuda.current_stream(dev)
-        if real_batch is not None:
-            rb = real_batch
-        elif self._prefetched is not None:
-            rb, self._prefetched = self._prefetched, None
-            main.wait_stream(self.stream_data)
-        else:
-            rb = self.sample_real()
         B_r = int(rb["num_clouds"])
-        rlabels = rb["labels"].to(_I32)
         xyz = self.image_syn[self.syn_rows].reshape(-1, 3)           # [G*ipc*npts, 3]; coordinates and features are the same tensor
         coords = torch.cat([self.syn_batch_col, xyz], 1)
         # cached layouts of the frozen weights are (re)built here, on the main stream, before the two passes fork
@@ -284,15 +356,16 @@ class FusedDistiller:
         sr, ss = self.stream_real, self.stream_syn
         sr.wait_stream(main)
         ss.wait_stream(main)
-        for t in rb.values():
-            if torch.is_tensor(t):
-                t.record_stream(sr)
+        if not static:
+            for t in rb.values():
+                if torch.is_tensor(t):
+                    t.record_stream(sr)
         with torch.cuda.stream(sr):
-            real = _Pass(self.network, rb["coordinates"], B_r, G, rb["cloud_group"], rb["group_cloud_off"])
+            real = _Pass(self.network, rb["coordinates"], B_r, G, rb["cloud_group"], rb["group_cloud_off"], rb.get("n_dev"), static)
         with torch.cuda.stream(ss):
-            syn = _Pass(self.network, coords, G * ipc, G, self.syn_group, self.syn_gco)
+            syn = _Pass(self.network, coords, G * ipc, G, self.syn_group, self.syn_gco, None, static)
         with torch.cuda.stream(sr):
-            real.run(rb["features"], rlabels, False)
+            real.run(rb["features"], rb["labels"], False)
         with torch.cuda.stream(ss):
             syn.run(xyz, self.syn_labels, True)
         syn._max_per = ipc
@@ -305,14 +378,73 @@ class FusedDistiller:
         grad = torch.zeros_like(self.image_syn)
         grad[self.syn_rows] = dfeats.reshape(G * ipc, npts, 3)
         self.last = {"per_class": loss_g, "grad": grad, "gw_real": real.gw, "gw_syn": syn.gw, "logits": (real.logits, syn.logits),
-                     "conv1_maps": [(real.maps[4], real.M[1]), (syn.maps[4], syn.M[1])], "rows": (real.M, syn.M)}
-        if apply_update:
-            n = self.image_syn.numel()
-            L.call("dd3d_sgd_momentum_clamp", L.ptr(self.image_syn), L.ptr(grad), L.ptr(self.momentum_buf), n, self.lr, self.momentum,
-                   1 if self.steps_done == 0 else 0, 0, 0.0, 27.0, L.stream())
+                     "conv1_maps": [(real.maps[4], real.M[1], real.cnt[1]), (syn.maps[4], syn.M[1], syn.cnt[1])], "passes": (real, syn)}
+        if self._apply_update:
+            # momentum_buf starts at zero, so the first step needs no special case (0.5 * 0 + g == g exactly)
+            L.call("dd3d_sgd_momentum_clamp", L.ptr(self.image_syn), L.ptr(grad), L.ptr(self.momentum_buf), self.image_syn.numel(), self.lr,
+                   self.momentum, 0, 0, 0.0, 27.0, L.stream())
+        return loss_g.sum()
+
+    def _static_body(self):
+        """clamp + on-device batch assembly + the step, all on fixed addresses with device-side sizes (what the graph captures)."""
+        st = self._static
+        self.clamp()
+        L.call("dd3d_gather_clouds", L.ptr(st.pool_xyz), L.ptr(st.pool_off), st.n_pool, L.ptr(st.ids), st.B, self.num_points, st.bound,
+               L.ptr(st.coords), L.ptr(st.feats), L.ptr(st.pt_off), L.ptr(st.n), L.ptr(st.err), L.stream())
+        rb = {"coordinates": st.coords, "features": st.feats, "labels": st.labels, "num_clouds": st.B, "cloud_group": st.cloud_group,
+              "group_cloud_off": st.gco, "n_dev": st.n}
+        with L.ws_scope(self._scope):
+            return self._compute(rb, True)
+
+    def row_counts(self):
+        """((M0,M1,M2) real, (M0,M1,M2) synthetic) of the last step (one device->host read in graph mode)."""
+        real, syn = self.last["passes"]
+        return tuple(tuple(int(x) for x in p.cm.counts[:3].tolist()) for p in (real, syn))
+
+    def check(self):
+        """Raise if any kernel of the last step flagged an error (graph mode defers these checks; eager mode raises in the step)."""
+        real, syn = self.last["passes"]
+        real.cm.check()
+        syn.cm.check()
+        if self._static is not None and int(self._static.err.item()) & 4:
+            raise RuntimeError("real-batch assembly: sample index outside the pool, or the batch exceeds its point bound")
+
+    def outer_step(self, real_batch=None, apply_update=True, force_eager=False):
+        """One matching step (mnist_distill.py:309-369 without evaluation/logging).  Returns the summed matching loss (0-d device
+        tensor; in graph mode it is a fixed buffer overwritten by the next step)."""
+        self._apply_update = apply_update
+        if self.use_graph and real_batch is None and apply_update:
+            if self._static is None:
+                self._build_static()
+            self._upload_ids()
+            if force_eager or self.steps_done == 0:
+                # the first step runs eagerly: it sizes the workspaces and builds the cached weight layouts the graph will reuse
+                loss = self._static_body()
+            else:
+                if self._graph is None:
+                    self._graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self._graph):
+                        self._graph_loss = self._static_body()
+                    self._graph_last = self.last
+                self._graph.replay()
+                loss, self.last = self._graph_loss, self._graph_last
             self.steps_done += 1
-        total = loss_g.sum()
-        if real_batch is None:
+            return loss
+        self.clamp()
+        main = torch.cuda.current_stream(self.device)
+        if real_batch is not None:
+            rb = real_batch
+        elif self._prefetched is not None:
+            rb, self._prefetched = self._prefetched, None
+            main.wait_stream(self.stream_data)
+        else:
+            rb = self.sample_real()
+        rb = dict(rb)
+        rb["labels"] = rb["labels"].to(_I32)
+        total = self._compute(rb, False)
+        if apply_update:
+            self.steps_done += 1
+        if real_batch is None and not self.use_graph:
             with torch.cuda.stream(self.stream_data):
                 self._prefetched = self.sample_real()
         return total

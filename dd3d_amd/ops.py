@@ -40,7 +40,7 @@ class VoxelMeanFn(Function):
         f = _c(feats)
         N, Cf = f.shape
         out = torch.empty((M, Cf), dtype=_F32, device=f.device)
-        L.call("dd3d_voxel_mean_fwd", L.ptr(f), N, Cf, L.ptr(cm.vox_off), L.ptr(cm.vox_pts), M, L.ptr(out), L.stream())
+        L.call("dd3d_voxel_mean_fwd", L.ptr(f), N, Cf, L.ptr(cm.vox_off), L.ptr(cm.vox_pts), M, None, L.ptr(out), L.stream())
         ctx.cm, ctx.N, ctx.Cf = cm, N, Cf
         return out
 
@@ -104,7 +104,7 @@ class SparseConvFn(Function):
         x, w = _c(X), _c(W)
         K, Cin, Cout = w.shape
         Y = torch.empty((M_out, Cout), dtype=_F32, device=x.device)
-        L.call("dd3d_conv_fwd", L.ptr(x), x.shape[0], Cin, L.ptr(w), Cout, L.ptr(nbr), ld, K, M_out, 0, L.ptr(Y), L.stream())
+        L.call("dd3d_conv_fwd", L.ptr(x), x.shape[0], Cin, L.ptr(w), Cout, L.ptr(nbr), ld, K, M_out, None, 0, L.ptr(Y), L.stream())
         ctx.save_for_backward(X, W)
         ctx.nbr, ctx.ld, ctx.M_out = nbr, ld, M_out
         return Y
@@ -118,7 +118,7 @@ class SparseConvFn(Function):
         if ctx.needs_input_grad[0]:
             dX = torch.empty_like(x)
             wk = transposed_kernel(W) if Cin == 128 else w
-            L.call("dd3d_conv_bwd_data", L.ptr(g), x.shape[0], Cout, L.ptr(wk), Cin, L.ptr(ctx.nbr), ctx.ld, K, L.ptr(dX), L.stream())
+            L.call("dd3d_conv_bwd_data", L.ptr(g), x.shape[0], None, Cout, L.ptr(wk), Cin, L.ptr(ctx.nbr), ctx.ld, K, L.ptr(dX), L.stream())
         if ctx.needs_input_grad[1]:
             dW = conv_bwd_weight(x, g, ctx.nbr, ctx.ld, ctx.M_out, _single_group(ctx.M_out, x.device), 1)[0]
         return dX, dW, None, None, None
@@ -169,7 +169,7 @@ class MaxPoolFn(Function):
         x = _c(X)
         out = torch.empty((M_out, x.shape[1]), dtype=_F32, device=x.device)
         arg = torch.empty((M_out, x.shape[1]), dtype=torch.int32, device=x.device)
-        L.call("dd3d_affine_relu_pool_fwd", L.ptr(x), None, None, 0, x.shape[1], L.ptr(kids), ld, kids.shape[0], M_out, L.ptr(out), L.ptr(arg), L.stream())
+        L.call("dd3d_affine_relu_pool_fwd", L.ptr(x), None, None, 0, x.shape[1], L.ptr(kids), ld, kids.shape[0], M_out, None, L.ptr(out), L.ptr(arg), L.stream())
         ctx.saved = (arg, parent, x)
         return out
 
@@ -223,7 +223,7 @@ class NormActPoolFn(Function):
         out = torch.empty((M_out, C), dtype=_F32, device=y.device)
         arg = torch.empty((M_out, C), dtype=torch.int32, device=y.device)
         L.call("dd3d_affine_relu_pool_fwd", L.ptr(xhat), L.ptr(_c(w).reshape(-1)), L.ptr(_c(b).reshape(-1)), 1, C, L.ptr(kids), ld, kids.shape[0],
-               M_out, L.ptr(out), L.ptr(arg), L.stream())
+               M_out, None, L.ptr(out), L.ptr(arg), L.stream())
         ctx.save_for_backward(Y, w, b)
         ctx.st = (xhat, inv_std, arg, parent, seg_off, B, gro, G)
         return out

@@ -31,7 +31,10 @@ class CoordinateManager:
 
     MAX_LEVELS = 8
 
-    def __init__(self, coords: torch.Tensor, num_clouds: Optional[int] = None):
+    def __init__(self, coords: torch.Tensor, num_clouds: Optional[int] = None, n_dev: Optional[torch.Tensor] = None):
+        """``n_dev`` (int32[1] on the device, optional): only the first ``*n_dev`` rows of ``coords`` are points; ``coords.shape[0]``
+        is then a bound.  With it (and without ever calling ``sync``) every map is built and consumed with device-side counts only,
+        which is what lets a whole step be captured into a HIP graph."""
         if coords.dim() != 2 or coords.shape[1] != 4:
             raise ValueError("coordinates must be [N,4] = (batch, c1, c2, c3)")
         coords = coords.detach().to(torch.float32).contiguous()
@@ -41,6 +44,7 @@ class CoordinateManager:
         self.N = int(coords.shape[0])
         self.coords = coords
         self._B = num_clouds
+        self.n_dev = n_dev
         self.counts = torch.zeros(self.MAX_LEVELS, dtype=_I32, device=self.device)
         self.err = torch.zeros(1, dtype=_I32, device=self.device)
         self.levels: Dict[int, _Level] = {}
@@ -77,16 +81,35 @@ class CoordinateManager:
         lv = self._new_level(1, N)
         q = torch.empty((max(N, 1), 4), dtype=_I32, device=self.device)
         L.call("dd3d_floor_coords", L.ptr(self.coords), N, L.ptr(q), L.stream())
-        self._unique(q, None, N, lv)
+        n_ptr = None if self.n_dev is None else self.n_dev.data_ptr()
+        self._unique(q, n_ptr, N, lv)
         # voxel -> points CSR for the feature mean
         self.vox_off = torch.empty(N + 1, dtype=_I32, device=self.device)
         self.vox_pts = torch.empty(max(N, 1), dtype=_I32, device=self.device)
         ws = L.workspace(int(L.lib.dd3d_csr_ws_bytes(N)), self.device)
-        L.call("dd3d_voxel_csr", L.ptr(lv.inv), None, N, self.counts[lv.slot:].data_ptr(), L.ptr(self.vox_off), L.ptr(self.vox_pts),
+        L.call("dd3d_voxel_csr", L.ptr(lv.inv), n_ptr, N, self.counts[lv.slot:].data_ptr(), L.ptr(self.vox_off), L.ptr(self.vox_pts),
                L.ptr(ws), ws.numel(), L.stream())
 
     def _count_ptr(self, lv: _Level):
         return None if lv.M is not None else self.counts[lv.slot:].data_ptr()
+
+    def count_ptr(self, stride: int) -> int:
+        """Device address of the row count of the level at ``stride`` (always valid, synced or not)."""
+        return self.counts[self.ensure_level(stride).slot:].data_ptr()
+
+    def rows_bound(self, stride: int) -> int:
+        return self._rows_bound(self.ensure_level(stride))
+
+    def check(self):
+        """Raise if a map kernel flagged an error (one device->host read; ``sync`` does the same)."""
+        self._raise_on(int(self.err.item()))
+
+    @staticmethod
+    def _raise_on(err: int):
+        if err & 1:
+            raise RuntimeError("coordinates are not grouped by ascending batch index (or a batch index is out of range)")
+        if err & 2:
+            raise IndexError("dense(): a voxel falls outside the requested dense shape")
 
     def _rows_bound(self, lv: _Level) -> int:
         return lv.M if lv.M is not None else lv.bound
@@ -146,12 +169,8 @@ class CoordinateManager:
         host = torch.cat([self.counts, self.err]).tolist()
         for lv in self.levels.values():
             lv.M = int(host[lv.slot])
-        err = host[-1]
         self._synced = True
-        if err & 1:
-            raise RuntimeError("coordinates are not grouped by ascending batch index (or a batch index is out of range)")
-        if err & 2:
-            raise IndexError("dense(): a voxel falls outside the requested dense shape")
+        self._raise_on(host[-1])
 
     def num_rows(self, stride: int) -> int:
         lv = self.ensure_level(stride)

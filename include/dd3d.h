@@ -75,19 +75,32 @@ int dd3d_segment_offsets(const int32_t* C, const int32_t* m_dev, int64_t bound, 
 int dd3d_dense_sites(const int32_t* C, const int32_t* m_dev, int64_t bound, const int32_t* cloud_group, int G, int B, int tensor_stride,
                      int E0, int E1, int E2, int32_t* gmin, int32_t* site, int32_t* vox_at, int32_t* err_dev, void* stream);
 
+/* Collated real batch straight from a point pool resident in HBM: cloud b = pool cloud ids[b] (its first `cap` points, pool
+ * order), rows (b, p) into coords[bound,4] and p into feats[bound,3]; pt_off[B+1]; *n_dev = rows written.  *err_dev |= 4 if an id
+ * is outside [0,n_pool) or the rows do not fit into `bound`.  pool_xyz[.,3] / pool_off[n_pool+1] are built once per dataset.
+ * replaces: get_images -> Mnist2Dreal.__getitem__ (argwhere(image==1)[:num_points]) -> minkowski_collate_fn / sparse_collate,
+ * mnist_distill.py:200-208, utils/Mnist2D.py:50-59, utils/MinkowskiCollate.py:4-15 */
+int dd3d_gather_clouds(const float* pool_xyz, const int32_t* pool_off, int n_pool, const int32_t* ids, int B, int cap, int64_t bound, float* coords,
+                       float* feats, int32_t* pt_off, int32_t* n_dev, int32_t* err_dev, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------------
  * (2) sparse convolution, gather-GEMM with atomic-free output (fp32 MFMA for Cin = 128)
  * ------------------------------------------------------------------------------------------------------------------- */
 
-/* Y[M_out,Cout] = sum_k X[nbr[k'][o]] . W[k],  W is [K,Cin,Cout], k' = mirror ? K-1-k : k.  K = 27, Cout = 128, Cin in {3,128}.
+/* Row counts: M / M_out / M_in is the number of rows, or -- when the nullable `m_dev` is given -- a BOUND, with the true count
+ * read from the device (rows beyond it are not touched).  Entry points that take group_row_off[G+1] / seg_off[B+1] device arrays
+ * always follow those (their chunking depends on group_row_off[G] only), so a bound may be passed there as well.  This is what
+ * lets a whole matching step be captured once into a HIP graph and replayed on batches of different sizes.
+ *
+ * Y[M_out,Cout] = sum_k X[nbr[k'][o]] . W[k],  W is [K,Cin,Cout], k' = mirror ? K-1-k : k.  K = 27, Cout = 128, Cin in {3,128}.
  * replaces: ME.MinkowskiConvolution forward (ConvolutionForwardGPU), models/MEConv.py:224 via :248 */
 int dd3d_conv_fwd(const float* X, int64_t M_in, int Cin, const float* W, int Cout, const int32_t* nbr, int64_t ld, int K, int64_t M_out,
-                  int mirror, float* Y, void* stream);
+                  const int32_t* m_dev, int mirror, float* Y, void* stream);
 
 /* dX[M,Cin] of a stride-1 convolution.  Cin = 128: pass the transposed kernel [K,Cout,Cin]; Cin = 3: pass W itself.
  * replaces: ConvolutionBackwardGPU (input gradient) reached by torch.autograd.grad / loss.backward, mnist_distill.py:349,359,365 */
-int dd3d_conv_bwd_data(const float* dY, int64_t M, int Cout, const float* W_or_Wt, int Cin, const int32_t* nbr, int64_t ld, int K, float* dX,
-                       void* stream);
+int dd3d_conv_bwd_data(const float* dY, int64_t M, const int32_t* m_dev, int Cout, const float* W_or_Wt, int Cin, const int32_t* nbr, int64_t ld,
+                       int K, float* dX, void* stream);
 
 /* dW[G,K,Cin,Cout], one kernel gradient per group of rows [group_row_off[g], group_row_off[g+1]) (device array of G+1 ints).
  * Deterministic: fixed row chunks -> partial slabs -> fixed-order reduction.  replaces: ConvolutionBackwardGPU (kernel gradient) */
@@ -104,7 +117,8 @@ int dd3d_transpose_kernel(const float* W, int K, int Cin, int Cout, float* Wt, v
 
 /* F0[v] = mean of the features of the points of voxel v (ascending point order).  replaces: MinkowskiSPMMAverageFunction inside
  * TensorField.sparse(), models/MEConv.py:247 -- backward is the only route by which gradient reaches the synthetic xyz */
-int dd3d_voxel_mean_fwd(const float* feats, int64_t N, int C, const int32_t* vox_off, const int32_t* vox_pts, int64_t M, float* F0, void* stream);
+int dd3d_voxel_mean_fwd(const float* feats, int64_t N, int C, const int32_t* vox_off, const int32_t* vox_pts, int64_t M, const int32_t* m_dev,
+                        float* F0, void* stream);
 int dd3d_voxel_mean_bwd(const float* dF0, int64_t M, int C, const int32_t* inv, const int32_t* vox_off, int64_t N, float* dfeats, void* stream);
 
 /* xhat = (Y - mean_b) / sqrt(var_b + 1e-8) per cloud b and channel (biased variance); inv_std[B,C].
@@ -115,7 +129,7 @@ int dd3d_inorm_bwd(const float* g, const float* xhat, const float* inv_std, cons
 /* out[o] = max over existing children of relu(xhat*w + b) (use_affine_relu = 0: plain max); arg = winning child row.
  * replaces: the affine of ME.MinkowskiInstanceNorm, ME.MinkowskiReLU and ME.MinkowskiMaxPooling forward, models/MEConv.py:225-227 */
 int dd3d_affine_relu_pool_fwd(const float* xhat, const float* w, const float* b, int use_affine_relu, int C, const int32_t* kids, int64_t ld,
-                              int Kp, int64_t M_out, float* out, int32_t* arg, void* stream);
+                              int Kp, int64_t M_out, const int32_t* m_dev, float* out, int32_t* arg, void* stream);
 
 /* backward of the same three ops for every input row; gw_w/gw_b[G,C] are the per-group affine gradients (nullable pair);
  * ga_out (nullable) keeps the ReLU-masked pooled gradient; ga_prev + gw_extra[G,C] (nullable pair) add ga_prev*gw_extra[group]. */

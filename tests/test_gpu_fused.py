@@ -101,3 +101,62 @@ def test_fused_sampling_is_seeded_and_runs_at_bench_shape():
     assert outs[0][0] == outs[1][0]
     assert torch.equal(outs[0][1], outs[1][1])
     assert np.isfinite(outs[0][0]).all()
+
+
+def test_gather_clouds_equals_collate():
+    """dd3d_gather_clouds (real batch assembled on the device from the point pool) against batch_from_images, which mirrors
+    Mnist2Dreal.__getitem__ + minkowski_collate_fn (utils/Mnist2D.py:50-59, utils/MinkowskiCollate.py:4-15): same rows, same order,
+    same cap; the error word flags a bad id and a bound that is too small."""
+    from dd3d_amd import _lib as L
+    from dd3d_amd.utils.Mnist2D import batch_from_images
+    imgs = stroke_digits(40, seed=9).to(DEV)
+    for cap in (250, 30):
+        pool = batch_from_images(imgs, torch.zeros(40, dtype=torch.long, device=DEV), cap)
+        cnt = torch.bincount(pool["coordinates"][:, 0].long(), minlength=40)
+        off = torch.cat([torch.zeros(1, dtype=torch.long, device=DEV), torch.cumsum(cnt, 0)]).to(torch.int32)
+        xyz = pool["features"].contiguous()
+        ids = torch.tensor([7, 7, 0, 39, 12, 3], dtype=torch.int32, device=DEV)
+        want = batch_from_images(imgs[ids.long()], torch.zeros(6, dtype=torch.long, device=DEV), cap)
+        bound = 6 * 250
+        coords = torch.full((bound, 4), -1.0, device=DEV)
+        feats = torch.full((bound, 3), -1.0, device=DEV)
+        pt_off = torch.zeros(7, dtype=torch.int32, device=DEV)
+        n = torch.zeros(1, dtype=torch.int32, device=DEV)
+        err = torch.zeros(1, dtype=torch.int32, device=DEV)
+        L.call("dd3d_gather_clouds", L.ptr(xyz), L.ptr(off), 40, L.ptr(ids), 6, cap, bound, L.ptr(coords), L.ptr(feats), L.ptr(pt_off), L.ptr(n),
+               L.ptr(err), L.stream())
+        N = int(n.item())
+        assert N == want["coordinates"].shape[0] and int(err.item()) == 0
+        assert torch.equal(coords[:N], want["coordinates"]) and torch.equal(feats[:N], want["features"])
+        assert float(coords[N:].max()) == -1.0  # nothing written beyond the count
+        # too small a bound, then an id outside the pool: flagged, never out of bounds
+        L.call("dd3d_gather_clouds", L.ptr(xyz), L.ptr(off), 40, L.ptr(ids), 6, cap, 64, L.ptr(coords), L.ptr(feats), L.ptr(pt_off), L.ptr(n),
+               L.ptr(err), L.stream())
+        assert int(err.item()) == 4 and int(n.item()) == 64
+        err.zero_()
+        bad = torch.tensor([1, 40, -1, 2, 2, 2], dtype=torch.int32, device=DEV)
+        L.call("dd3d_gather_clouds", L.ptr(xyz), L.ptr(off), 40, L.ptr(bad), 6, cap, bound, L.ptr(coords), L.ptr(feats), L.ptr(pt_off), L.ptr(n),
+               L.ptr(err), L.stream())
+        assert int(err.item()) == 4
+
+
+@pytest.mark.parametrize("metric", ["modmse", "ours"])
+def test_graph_replay_is_bitwise_the_eager_step(metric):
+    """The captured HIP graph (bound-sized launches, device-side row counts, on-device batch assembly) against the eager step with
+    exact sizes: same seed => the same samples => bit-identical losses and synthetic points over several steps of different sizes."""
+    from dd3d_amd.fused_step import FusedDistiller
+    from dd3d_amd.synthetic import mnist3d_like
+    images, _, idx = mnist3d_like(4, 40, seed=3)
+    syn = init_synthetic(4, 3, 250, seed=1)
+    kw = dict(ipc=3, num_classes=4, batch_size=24, dist_opt=metric, device=DEV, seed=11, image_syn=syn)
+    fg = FusedDistiller(images, idx, _net(), graph=True, **kw)
+    fe = FusedDistiller(images, idx, _net(), graph=False, **kw)
+    sizes = set()
+    for step in range(5):
+        lg, le = fg.outer_step().item(), fe.outer_step().item()
+        assert lg == le, f"step {step}: graph {lg} vs eager {le}"
+        assert torch.equal(fg.image_syn, fe.image_syn)
+        assert torch.equal(fg.last["grad"], fe.last["grad"])
+        sizes.add(fg.row_counts()[0])
+    fg.check()
+    assert fg._graph is not None and len(sizes) > 1  # the graph really replayed over batches of different sizes

@@ -1,7 +1,7 @@
 """Micro-benchmark of the 128-channel sparse convolution on the cfg2 real batch (10 x 256 stroke digits) and the synthetic batch.
 usage: python tools_convbench.py   (set DD3D_CONV128_DENSE=1 to time the dense-tile kernel instead)"""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dd3d_amd import _lib as L
 from dd3d_amd.sparse import CoordinateManager
 from dd3d_amd.synthetic import mnist3d_like, init_synthetic
@@ -22,7 +22,7 @@ for name, coords, B in (("real", b["coordinates"], 2560), ("syn", sc, 100)):
     W = torch.randn(27, 128, 128, device=dev) * 0.05
     Y = torch.empty(M, 128, device=dev)
     def run():
-        L.call("dd3d_conv_fwd", L.ptr(X), M, 128, L.ptr(W), 128, L.ptr(nbr), ld, 27, M, 0, L.ptr(Y), L.stream())
+        L.call("dd3d_conv_fwd", L.ptr(X), M, 128, L.ptr(W), 128, L.ptr(nbr), ld, 27, M, None, 0, L.ptr(Y), L.stream())
     for _ in range(5): run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -1,6 +1,6 @@
 """Where does the host spend its time inside one fused step?  (wall-clock marks, no extra syncs)"""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dd3d_amd.fused_step as fs
 from dd3d_amd import _lib as L
 from dd3d_amd.models.MEConv import MEConvExp
