@@ -283,34 +283,78 @@ __global__ void k_slab_reduce(const f32x4* __restrict__ slabs, const int* __rest
 // ---------------------------------------------------------------------------------------------
 // Cin = 3, Cout = 128 (first layer): bandwidth kernels on the VALU
 // ---------------------------------------------------------------------------------------------
+// Y[o][:] = sum_k X[nbr[k][o]][0:3] . W[k][0:3][:] as a [64 x 96] x [96 x 128] product per tile on the fp32 matrix cores: the
+// im2col tile A[o][3k+ci] is gathered into LDS with coalesced neighbour-table reads (64 consecutive rows per offset), W sits in
+// LDS for the whole block (TILES tiles), and MFMA steps whose two columns belong to offsets without any neighbour in the tile are
+// skipped (z = 0 clouds only ever have 9 of the 27 offsets).  Column order inside a 32-chunk follows the MFMA operand layout
+// (lane half h supplies column 16h + s at step s), identical for A and W.
+template <int TILES>
 __global__ __launch_bounds__(256) void k_conv3_fwd(const float* __restrict__ X, const float* __restrict__ W /*[K][3][128]*/, const int* __restrict__ nbr,
-                                                   int64_t ld, int K, int M_bound, const int* __restrict__ m_dev, int rows_per_block, float* __restrict__ Y) {
-    __shared__ f32x4 Ws4[27 * 3 * 32];
-    const int tid = threadIdx.x;
+                                                   int64_t ld, int K, int M_bound, const int* __restrict__ m_dev, float* __restrict__ Y) {
+    constexpr int LDA = 97;
+    __shared__ float Ws[96 * 128];
+    __shared__ float As[64 * LDA];
+    __shared__ unsigned s_kmask;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int i32 = lane & 31, h = lane >> 5;
     const int M_out = m_dev ? min(*m_dev, M_bound) : M_bound;
-    if ((int64_t)blockIdx.x * rows_per_block >= M_out) return;
-    const f32x4* W4 = (const f32x4*)W;
-    for (int i = tid; i < K * 3 * 32; i += 256) Ws4[i] = W4[i];
-    __syncthreads();
-    const int c4 = tid & 31, rl = tid >> 5;
-    const int64_t row0 = (int64_t)blockIdx.x * rows_per_block;
-    f32x4* Y4 = (f32x4*)Y;
-    for (int it = 0; it < rows_per_block; it += 8) {
-        int64_t row = row0 + it + rl;
-        bool live = row < M_out;
-        int mynb = (live && c4 < K) ? nbr[(int64_t)c4 * ld + row] : -1;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < K; ++k) {
-            int nb = __shfl(mynb, k, 32);
-            if (nb >= 0) {
-                const float* x = X + (int64_t)nb * 3;
-                float x0 = x[0], x1 = x[1], x2 = x[2];
-                acc += x0 * Ws4[(k * 3 + 0) * 32 + c4];
-                acc += x1 * Ws4[(k * 3 + 1) * 32 + c4];
-                acc += x2 * Ws4[(k * 3 + 2) * 32 + c4];
+    const int64_t first = (int64_t)blockIdx.x * TILES * 64;
+    if (first >= M_out) return;
+    for (int i = tid; i < 96 * 128; i += 256) Ws[i] = i < K * 3 * 128 ? W[i] : 0.f;
+    for (int i = tid; i < 64 * LDA; i += 256) As[i] = 0.f;  // columns 81..96 stay zero
+    const int sr = tid & 63, sk = tid >> 6;                 // staging: row of the tile, offset lane (4 lanes walk the 27 offsets)
+    for (int t = 0; t < TILES; ++t) {
+        const int64_t row0 = first + (int64_t)t * 64;
+        if (row0 >= M_out) break;
+        if (tid == 0) s_kmask = 0;
+        __syncthreads();  // previous tile's MFMA reads of As are done; W / zero fill visible
+        unsigned mymask = 0;
+        const int64_t row = row0 + sr;
+#pragma unroll
+        for (int kk = 0; kk < 7; ++kk) {
+            const int k = sk + kk * 4;
+            if (k < K) {
+                const int nb = row < M_out ? nbr[(int64_t)k * ld + row] : -1;
+                float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+                if (nb >= 0) {
+                    const float* x = X + (int64_t)nb * 3;
+                    x0 = x[0]; x1 = x[1]; x2 = x[2];
+                    mymask |= 1u << k;
+                }
+                As[sr * LDA + k * 3 + 0] = x0;
+                As[sr * LDA + k * 3 + 1] = x1;
+                As[sr * LDA + k * 3 + 2] = x2;
             }
         }
-        if (live) Y4[row * 32 + c4] = acc;
+        if (mymask) atomicOr(&s_kmask, mymask);
+        __syncthreads();
+        const unsigned kmask = __builtin_amdgcn_readfirstlane(s_kmask);  // wave-uniform: the step skipping below is a scalar branch
+        f32x16 acc[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) {
+                const int j0 = q * 32 + s2, j1 = j0 + 16;  // the two columns of this MFMA step (lane halves h = 0, 1)
+                if (!(((kmask >> (j0 / 3)) | (kmask >> (j1 / 3))) & 1u)) continue;
+                const int j = h ? j1 : j0;
+                const float bv = Ws[j * 128 + wid * 32 + i32];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const float av = As[(m * 32 + i32) * LDA + j];
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m], 0, 0, 0);
+                }
+            }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t orow = row0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (orow < M_out) Y[orow * 128 + wid * 32 + i32] = acc[m][r];
+            }
     }
 }
 
@@ -465,8 +509,7 @@ DD3D_API int dd3d_conv_fwd(const float* X, int64_t M_in, int Cin, const float* W
     hipStream_t st = (hipStream_t)stream;
     if (Cin == 3) {
         if (mirror) return DD3D_EARG;
-        const int rpb = 64;
-        k_conv3_fwd<<<dim3((unsigned)ceil_div64(M_out, rpb)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, rpb, Y);
+        k_conv3_fwd<2><<<dim3((unsigned)ceil_div64(M_out, 128)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, Y);
     } else if (M_out >= 128 * 512) {
         k_conv128<128, 2, 2><<<dim3((unsigned)ceil_div64(M_out, 128)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y);
     } else {

@@ -188,22 +188,22 @@ __global__ void k_softmax_ce(const float* __restrict__ logits, const int* __rest
     cloud_loss[b] = (lse - z[y]) * inv;
 }
 
+// one wave per (group, column): lanes take clouds b0+lane, b0+lane+64, ... in order, then a fixed shuffle tree -> deterministic
 __global__ void k_group_sum(const float* __restrict__ v, const int* __restrict__ group_cloud_off, int G, float* __restrict__ out) {
-    int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= G) return;
+    int g = blockIdx.x;
     float s = 0.f;
-    for (int b = group_cloud_off[g]; b < group_cloud_off[g + 1]; ++b) s += v[b];
-    out[g] = s;
+    for (int b = group_cloud_off[g] + threadIdx.x; b < group_cloud_off[g + 1]; b += 64) s += v[b];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[g] = s;
 }
 
-// out[g][j] = sum over the clouds b of group g of v[b][j], in cloud order (deterministic)
+// out[g][j] = sum over the clouds b of group g of v[b][j]: one wave per (g, j), same fixed order as k_group_sum
 __global__ void k_group_sum_rows(const float* __restrict__ v, const int* __restrict__ group_cloud_off, int G, int J, float* __restrict__ out) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= G * J) return;
-    int g = t / J, j = t - g * J;
+    int g = blockIdx.x / J, j = blockIdx.x - g * J;
     float s = 0.f;
-    for (int b = group_cloud_off[g]; b < group_cloud_off[g + 1]; ++b) s += v[(int64_t)b * J + j];
-    out[t] = s;
+    for (int b = group_cloud_off[g] + threadIdx.x; b < group_cloud_off[g + 1]; b += 64) s += v[(int64_t)b * J + j];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
 
 // second order: dlogits = (softmax(z) - onehot)/B_g ; given u = dL/d(dlogits) -> dz = p * (u - <p,u>) / B_g
@@ -500,14 +500,14 @@ DD3D_API int dd3d_softmax_ce(const float* logits, const int32_t* labels, const i
     if (!logits || !labels || !dlogits || !cloud_loss) return DD3D_EARG;
     hipStream_t st = (hipStream_t)stream;
     k_softmax_ce<<<dim3((B + 63) / 64), 64, 0, st>>>(logits, labels, cloud_group, group_cloud_off, B, J, prob, dlogits, cloud_loss);
-    if (loss_g) k_group_sum<<<dim3((G + 63) / 64), 64, 0, st>>>(cloud_loss, group_cloud_off, G, loss_g);
+    if (loss_g) k_group_sum<<<dim3(G), 64, 0, st>>>(cloud_loss, group_cloud_off, G, loss_g);
     DD3D_CHECK_LAUNCH();
     return 0;
 }
 
 DD3D_API int dd3d_group_sum_rows(const float* v, const int32_t* group_cloud_off, int G, int J, float* out, void* stream) {
     if (G <= 0 || J <= 0 || !v || !group_cloud_off || !out) return DD3D_EARG;
-    k_group_sum_rows<<<dim3((G * J + 63) / 64), 64, 0, (hipStream_t)stream>>>(v, group_cloud_off, G, J, out);
+    k_group_sum_rows<<<dim3(G * J), 64, 0, (hipStream_t)stream>>>(v, group_cloud_off, G, J, out);
     DD3D_CHECK_LAUNCH();
     return 0;
 }

@@ -61,50 +61,102 @@ __device__ __forceinline__ f32x4 block_colsum(f32x4 v, f32x4* s_red /*[8*32]*/) 
     return s;
 }
 
-__global__ __launch_bounds__(256) void k_inorm_fwd(const f32x4* __restrict__ Y, const int* __restrict__ seg_off, f32x4* __restrict__ xhat,
-                                                   f32x4* __restrict__ inv_std) {
-    __shared__ f32x4 s_red[256];
-    const int b = blockIdx.x, c4 = blockIdx.y * 8 + (threadIdx.x & 7), rl = threadIdx.x >> 3;
+// One workgroup per cloud: RL row-lanes x 32 float4 channel-lanes, i.e. whole 512-B rows.  Every thread keeps up to CACHE of its
+// rows in registers, so a cloud of <= RL*CACHE rows is read from HBM exactly once (mean, variance and the normalised write all
+// work on the registers); longer clouds re-read their tail (L2).  Sums run over a thread's rows in ascending order, then over the
+// row-lanes in lane order: deterministic.
+template <int RL>
+__device__ __forceinline__ f32x4 cloud_colsum(f32x4 v, f32x4* s_red /*[RL*32]*/) {
+    const int c4 = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    s_red[rl * 32 + c4] = v;
+    __syncthreads();
+    f32x4 s = s_red[c4];
+#pragma unroll 4
+    for (int j = 1; j < RL; ++j) s += s_red[j * 32 + c4];
+    __syncthreads();
+    return s;
+}
+
+template <int RL, int CACHE>
+__global__ __launch_bounds__(RL * 32) void k_inorm_fwd(const f32x4* __restrict__ Y, const int* __restrict__ seg_off, f32x4* __restrict__ xhat,
+                                                       f32x4* __restrict__ inv_std) {
+    __shared__ f32x4 s_red[RL * 32];
+    const int b = blockIdx.x, c4 = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const int r0 = seg_off[b], r1 = seg_off[b + 1];
     const int n = r1 - r0;
     if (n <= 0) {
         if (rl == 0) inv_std[(int64_t)b * 32 + c4] = (f32x4){0.f, 0.f, 0.f, 0.f};
         return;
     }
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int r = r0 + rl; r < r1; r += 32) s += Y[(int64_t)r * 32 + c4];
-    f32x4 mean = quarter_colsum(s, s_red) / (float)n;
-    f32x4 q = {0.f, 0.f, 0.f, 0.f};
-    for (int r = r0 + rl; r < r1; r += 32) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 v[CACHE];
+    f32x4 s = zero;
+#pragma unroll
+    for (int i = 0; i < CACHE; ++i) {
+        int r = r0 + rl + i * RL;
+        v[i] = r < r1 ? Y[(int64_t)r * 32 + c4] : zero;
+        s += v[i];
+    }
+    for (int r = r0 + rl + CACHE * RL; r < r1; r += RL) s += Y[(int64_t)r * 32 + c4];
+    const f32x4 mean = cloud_colsum<RL>(s, s_red) / (float)n;
+    f32x4 q = zero;
+#pragma unroll
+    for (int i = 0; i < CACHE; ++i) {
+        int r = r0 + rl + i * RL;
+        f32x4 d = v[i] - mean;
+        if (r < r1) q += d * d;
+    }
+    for (int r = r0 + rl + CACHE * RL; r < r1; r += RL) {
         f32x4 d = Y[(int64_t)r * 32 + c4] - mean;
         q += d * d;
     }
-    f32x4 var = quarter_colsum(q, s_red) / (float)n;
+    const f32x4 var = cloud_colsum<RL>(q, s_red) / (float)n;
     f32x4 is;
 #pragma unroll
     for (int j = 0; j < 4; ++j) is[j] = 1.0f / sqrtf(var[j] + 1e-8f);
     if (rl == 0) inv_std[(int64_t)b * 32 + c4] = is;
-    for (int r = r0 + rl; r < r1; r += 32) xhat[(int64_t)r * 32 + c4] = (Y[(int64_t)r * 32 + c4] - mean) * is;
+#pragma unroll
+    for (int i = 0; i < CACHE; ++i) {
+        int r = r0 + rl + i * RL;
+        if (r < r1) xhat[(int64_t)r * 32 + c4] = (v[i] - mean) * is;
+    }
+    for (int r = r0 + rl + CACHE * RL; r < r1; r += RL) xhat[(int64_t)r * 32 + c4] = (Y[(int64_t)r * 32 + c4] - mean) * is;
 }
 
 // dY = (g - xhat * mean(g*xhat) - mean(g)) * inv_std     (MinkowskiInstanceNormFunction.backward)
-__global__ __launch_bounds__(256) void k_inorm_bwd(const f32x4* __restrict__ g, const f32x4* __restrict__ xhat, const f32x4* __restrict__ inv_std,
-                                                   const int* __restrict__ seg_off, f32x4* __restrict__ dY) {
-    __shared__ f32x4 s_red[256];
-    const int b = blockIdx.x, c4 = blockIdx.y * 8 + (threadIdx.x & 7), rl = threadIdx.x >> 3;
+template <int RL, int CACHE>
+__global__ __launch_bounds__(RL * 32) void k_inorm_bwd(const f32x4* __restrict__ g, const f32x4* __restrict__ xhat, const f32x4* __restrict__ inv_std,
+                                                       const int* __restrict__ seg_off, f32x4* __restrict__ dY) {
+    __shared__ f32x4 s_red[RL * 32];
+    const int b = blockIdx.x, c4 = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const int r0 = seg_off[b], r1 = seg_off[b + 1];
     const int n = r1 - r0;
     if (n <= 0) return;
-    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-    for (int r = r0 + rl; r < r1; r += 32) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 vg[CACHE], vx[CACHE];
+    f32x4 s1 = zero, s2 = zero;
+#pragma unroll
+    for (int i = 0; i < CACHE; ++i) {
+        int r = r0 + rl + i * RL;
+        vg[i] = r < r1 ? g[(int64_t)r * 32 + c4] : zero;
+        vx[i] = r < r1 ? xhat[(int64_t)r * 32 + c4] : zero;
+        s1 += vg[i];
+        s2 += vg[i] * vx[i];
+    }
+    for (int r = r0 + rl + CACHE * RL; r < r1; r += RL) {
         f32x4 gg = g[(int64_t)r * 32 + c4];
         s1 += gg;
         s2 += gg * xhat[(int64_t)r * 32 + c4];
     }
-    f32x4 m1 = quarter_colsum(s1, s_red) / (float)n;
-    f32x4 m2 = quarter_colsum(s2, s_red) / (float)n;
-    f32x4 is = inv_std[(int64_t)b * 32 + c4];
-    for (int r = r0 + rl; r < r1; r += 32) {
+    const f32x4 m1 = cloud_colsum<RL>(s1, s_red) / (float)n;
+    const f32x4 m2 = cloud_colsum<RL>(s2, s_red) / (float)n;
+    const f32x4 is = inv_std[(int64_t)b * 32 + c4];
+#pragma unroll
+    for (int i = 0; i < CACHE; ++i) {
+        int r = r0 + rl + i * RL;
+        if (r < r1) dY[(int64_t)r * 32 + c4] = (vg[i] - vx[i] * m2 - m1) * is;
+    }
+    for (int r = r0 + rl + CACHE * RL; r < r1; r += RL) {
         int64_t o = (int64_t)r * 32 + c4;
         dY[o] = (g[o] - xhat[o] * m2 - m1) * is;
     }
@@ -220,6 +272,111 @@ __global__ __launch_bounds__(256) void k_arp_reduce(const f32x4* __restrict__ pa
     }
 }
 
+// Backward of pool -> ReLU -> affine -> instance norm in ONE pass over a cloud (k_arp_bwd followed by k_inorm_bwd, without the
+// round trip of g_xhat through HBM): the thread's rows of g_xhat and xhat stay in registers between the statistics and the final
+// write.  Per-cloud partial sums of ga*xhat / ga go to part[b][2][32]; k_cloud_group_sum folds them per group in cloud order.
+template <int RL, int CACHE>
+__global__ __launch_bounds__(RL * 32) void k_arp_inorm_bwd(const f32x4* __restrict__ g_pool, const int4* __restrict__ arg, const int* __restrict__ parent,
+                                                           const f32x4* __restrict__ xhat, const f32x4* __restrict__ inv_std,
+                                                           const f32x4* __restrict__ w, const f32x4* __restrict__ bias,
+                                                           const int* __restrict__ seg_off, const int* __restrict__ cloud_group,
+                                                           f32x4* __restrict__ dY, f32x4* __restrict__ ga_out, const f32x4* __restrict__ ga_prev,
+                                                           const f32x4* __restrict__ gw_extra, f32x4* __restrict__ part /*[B][2][32] or null*/) {
+    __shared__ f32x4 s_red[RL * 32];
+    const int b = blockIdx.x, c4 = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int r0 = seg_off[b], r1 = seg_off[b + 1];
+    const int n = r1 - r0;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    if (n <= 0) {
+        if (part && rl == 0) {
+            part[((int64_t)b * 2 + 0) * 32 + c4] = zero;
+            part[((int64_t)b * 2 + 1) * 32 + c4] = zero;
+        }
+        return;
+    }
+    const f32x4 ww = w[c4], bb = bias[c4];
+    f32x4 ex = zero;
+    if (gw_extra) ex = gw_extra[(int64_t)(cloud_group ? cloud_group[b] : 0) * 32 + c4];
+    // ga (ReLU-masked pooled gradient) and g_xhat of row i
+    auto row = [&](int i, f32x4& xh, f32x4& ga, f32x4& gx) {
+        const int64_t po = (int64_t)parent[i] * 32 + c4, io = (int64_t)i * 32 + c4;
+        const int4 a = arg[po];
+        const f32x4 gp = g_pool[po];
+        xh = xhat[io];
+        ga[0] = a.x == i ? gp[0] : 0.f;
+        ga[1] = a.y == i ? gp[1] : 0.f;
+        ga[2] = a.z == i ? gp[2] : 0.f;
+        ga[3] = a.w == i ? gp[3] : 0.f;
+        const f32x4 y = xh * ww + bb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ga[j] = y[j] > 0.f ? ga[j] : 0.f;
+        gx = ga * ww;
+        if (ga_prev) gx += ga_prev[io] * ex;
+    };
+    f32x4 vg[CACHE], vx[CACHE];
+    f32x4 sw = zero, sb = zero, s1 = zero, s2 = zero;
+#pragma unroll
+    for (int i = 0; i < CACHE; ++i) {
+        const int r = r0 + rl + i * RL;
+        vg[i] = zero;
+        vx[i] = zero;
+        if (r < r1) {
+            f32x4 ga;
+            row(r, vx[i], ga, vg[i]);
+            if (ga_out) ga_out[(int64_t)r * 32 + c4] = ga;
+            sw += ga * vx[i];
+            sb += ga;
+            s1 += vg[i];
+            s2 += vg[i] * vx[i];
+        }
+    }
+    for (int r = r0 + rl + CACHE * RL; r < r1; r += RL) {
+        f32x4 xh, ga, gx;
+        row(r, xh, ga, gx);
+        if (ga_out) ga_out[(int64_t)r * 32 + c4] = ga;
+        sw += ga * xh;
+        sb += ga;
+        s1 += gx;
+        s2 += gx * xh;
+    }
+    const f32x4 m1 = cloud_colsum<RL>(s1, s_red) / (float)n;
+    const f32x4 m2 = cloud_colsum<RL>(s2, s_red) / (float)n;
+    if (part) {
+        const f32x4 tw = cloud_colsum<RL>(sw, s_red);
+        const f32x4 tb = cloud_colsum<RL>(sb, s_red);
+        if (rl == 0) {
+            part[((int64_t)b * 2 + 0) * 32 + c4] = tw;
+            part[((int64_t)b * 2 + 1) * 32 + c4] = tb;
+        }
+    }
+    const f32x4 is = inv_std[(int64_t)b * 32 + c4];
+#pragma unroll
+    for (int i = 0; i < CACHE; ++i) {
+        const int r = r0 + rl + i * RL;
+        if (r < r1) dY[(int64_t)r * 32 + c4] = (vg[i] - vx[i] * m2 - m1) * is;
+    }
+    for (int r = r0 + rl + CACHE * RL; r < r1; r += RL) {
+        f32x4 xh, ga, gx;
+        row(r, xh, ga, gx);
+        dY[(int64_t)r * 32 + c4] = (gx - xh * m2 - m1) * is;
+    }
+}
+
+// out_w/out_b[g][c4] = sum over the clouds of group g of part[b][0/1][c4]; 4 cloud-lanes take clouds in order, combined in lane order
+__global__ __launch_bounds__(256) void k_cloud_group_sum(const f32x4* __restrict__ part, const int* __restrict__ group_cloud_off, f32x4* __restrict__ gw_w,
+                                                         f32x4* __restrict__ gw_b) {
+    __shared__ f32x4 s_red[256];
+    const int g = blockIdx.x, c4 = threadIdx.x & 31, j = (threadIdx.x >> 5) & 1, sl = threadIdx.x >> 6;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int b = group_cloud_off[g] + sl; b < group_cloud_off[g + 1]; b += 4) s += part[((int64_t)b * 2 + j) * 32 + c4];
+    s_red[threadIdx.x] = s;
+    __syncthreads();
+    if (sl == 0) {
+        const int t = threadIdx.x;
+        (j == 0 ? gw_w : gw_b)[(int64_t)g * 32 + c4] = s_red[t] + s_red[t + 64] + s_red[t + 128] + s_red[t + 192];
+    }
+}
+
 // g_xhat[i] = ga[i] * gw[group(i)]  (outer-backward seed through an affine weight gradient)
 __global__ void k_scale_rows_by_group(const f32x4* __restrict__ ga, const f32x4* __restrict__ gw, const int* __restrict__ group_row_off, int G,
                                       int64_t M, f32x4* __restrict__ out) {
@@ -257,7 +414,7 @@ DD3D_API int dd3d_inorm_fwd(const float* Y, const int32_t* seg_off, int B, int C
     if (B < 0 || C != 128) return DD3D_EARG;
     if (B == 0) return 0;
     if (!Y || !seg_off || !xhat || !inv_std) return DD3D_EARG;
-    k_inorm_fwd<<<dim3(B, 4), 256, 0, (hipStream_t)stream>>>((const f32x4*)Y, seg_off, (f32x4*)xhat, (f32x4*)inv_std);
+    k_inorm_fwd<16, 8><<<dim3(B), 512, 0, (hipStream_t)stream>>>((const f32x4*)Y, seg_off, (f32x4*)xhat, (f32x4*)inv_std);
     DD3D_CHECK_LAUNCH();
     return 0;
 }
@@ -266,7 +423,7 @@ DD3D_API int dd3d_inorm_bwd(const float* g, const float* xhat, const float* inv_
     if (B < 0 || C != 128) return DD3D_EARG;
     if (B == 0) return 0;
     if (!g || !xhat || !inv_std || !seg_off || !dY) return DD3D_EARG;
-    k_inorm_bwd<<<dim3(B, 4), 256, 0, (hipStream_t)stream>>>((const f32x4*)g, (const f32x4*)xhat, (const f32x4*)inv_std, seg_off, (f32x4*)dY);
+    k_inorm_bwd<16, 8><<<dim3(B), 512, 0, (hipStream_t)stream>>>((const f32x4*)g, (const f32x4*)xhat, (const f32x4*)inv_std, seg_off, (f32x4*)dY);
     DD3D_CHECK_LAUNCH();
     return 0;
 }
@@ -319,6 +476,31 @@ DD3D_API int dd3d_scale_rows_by_group(const float* ga, const float* gw, const in
     if (!ga || !gw || !out) return DD3D_EARG;
     k_scale_rows_by_group<<<dim3((unsigned)ceil_div64(M, 8)), 256, 0, (hipStream_t)stream>>>((const f32x4*)ga, (const f32x4*)gw, group_row_off, G, M,
                                                                                             (f32x4*)out);
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}
+
+DD3D_API int64_t dd3d_arp_inorm_bwd_ws_bytes(int B) { return align_up64((int64_t)(B > 0 ? B : 1) * 2 * 128 * 4, 256); }
+
+// dY[M_in,128] = backward of (instance norm -> affine -> ReLU -> max pool) w.r.t. the norm's input, per cloud, in one pass.
+// gw_w/gw_b[G,128] (nullable pair): per-group affine gradients; ga_out (nullable): ReLU-masked pooled gradient;
+// ga_prev + gw_extra[G,128] (nullable pair): adds ga_prev * gw_extra[group] to the gradient w.r.t. xhat first.
+DD3D_API int dd3d_arp_inorm_bwd(const float* g_pool, const int32_t* arg, const int32_t* parent, const float* xhat, const float* inv_std,
+                                const float* w, const float* b, int C, const int32_t* seg_off, int B, const int32_t* cloud_group,
+                                const int32_t* group_cloud_off, int G, float* dY, float* ga_out, const float* ga_prev, const float* gw_extra,
+                                float* gw_w, float* gw_b, void* ws, int64_t ws_bytes, void* stream) {
+    if (B < 0 || C != 128 || G <= 0 || !w || !b || ((ga_prev == nullptr) != (gw_extra == nullptr)) || ((gw_w == nullptr) != (gw_b == nullptr)) ||
+        (gw_w && !group_cloud_off) || (G > 1 && gw_extra && !cloud_group))
+        return DD3D_EARG;
+    if (gw_w && (ws_bytes < dd3d_arp_inorm_bwd_ws_bytes(B) || !ws)) return DD3D_EWS;
+    hipStream_t st = (hipStream_t)stream;
+    if (B > 0) {
+        if (!g_pool || !arg || !parent || !xhat || !inv_std || !seg_off || !dY) return DD3D_EARG;
+        k_arp_inorm_bwd<32, 4><<<dim3(B), 1024, 0, st>>>((const f32x4*)g_pool, (const int4*)arg, parent, (const f32x4*)xhat, (const f32x4*)inv_std,
+                                                        (const f32x4*)w, (const f32x4*)b, seg_off, cloud_group, (f32x4*)dY, (f32x4*)ga_out,
+                                                        (const f32x4*)ga_prev, (const f32x4*)gw_extra, gw_w ? (f32x4*)ws : nullptr);
+    }
+    if (gw_w) k_cloud_group_sum<<<dim3(G), 256, 0, st>>>((const f32x4*)ws, group_cloud_off, (f32x4*)gw_w, (f32x4*)gw_b);
     DD3D_CHECK_LAUNCH();
     return 0;
 }

@@ -17,6 +17,7 @@ are exactly those that torch autograd produces around MinkowskiEngine's opaque b
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import List, Optional
 
 import numpy as np
@@ -118,30 +119,28 @@ class _Pass:
                g_cw.numel(), st)
         gP1 = _empty((M2, 128), dev)
         L.call("dd3d_sparse_linear_bwd_x", L.ptr(dl), L.ptr(dp.site), L.ptr(dp.seg_off), B, 128, None, L.ptr(Wsm), sst, J, 0, L.ptr(gP1), st)
-        gx1, self.ga1, g_w5, g_b5 = self._arp_bwd(gP1, arg1, cm.parent(4), xh1, w5, b5, gro2, M1, keep_ga, True)
-        gY1 = _empty((M1, 128), dev)
-        L.call("dd3d_inorm_bwd", L.ptr(gx1), L.ptr(xh1), L.ptr(is1), L.ptr(seg2), B, 128, L.ptr(gY1), st)
+        gY1, self.ga1, g_w5, g_b5 = self._arp_inorm_bwd(gP1, arg1, cm.parent(4), xh1, is1, w5, b5, seg2, M1, keep_ga, True)
         g_W1 = self._bww(P0, 128, gY1, k1, ld1, M1, gro2)
         gP0 = _empty((M1, 128), dev)
         L.call("dd3d_conv_bwd_data", L.ptr(gY1), M1, c1, 128, L.ptr(W1t), 128, L.ptr(k1), ld1, 27, L.ptr(gP0), st)
-        gx0, self.ga0, g_w1, g_b1 = self._arp_bwd(gP0, arg0, cm.parent(2), xh0, w1, b1, gro1, M0, keep_ga, True)
-        gY0 = _empty((M0, 128), dev)
-        L.call("dd3d_inorm_bwd", L.ptr(gx0), L.ptr(xh0), L.ptr(is0), L.ptr(seg1), B, 128, L.ptr(gY0), st)
+        gY0, self.ga0, g_w1, g_b1 = self._arp_inorm_bwd(gP0, arg0, cm.parent(2), xh0, is0, w1, b1, seg1, M0, keep_ga, True)
         g_W0 = self._bww(F0, 3, gY0, k0, ld0, M0, gro1)
         # order of network.parameters()
         self.gw = [g_W0, g_w1, g_b1, g_W1, g_w5, g_b5, g_cw, g_cb]
         return self
 
-    def _arp_bwd(self, g_pool, arg, parent, xhat, w, b, gro, M_in, keep_ga, want_gw, ga_prev=None, gw_extra=None):
-        dev, G = self.dev, self.G
-        gx = _empty((M_in, 128), dev)
+    def _arp_inorm_bwd(self, g_pool, arg, parent, xhat, inv_std, w, b, seg, M_in, keep_ga, want_gw, ga_prev=None, gw_extra=None):
+        """Backward of max-pool -> ReLU -> affine -> instance norm in one pass per cloud: (dY, ga, d weight [G,128], d bias [G,128])."""
+        dev, G, B = self.dev, self.G, self.B
+        dY = _empty((M_in, 128), dev)
         ga = _empty((M_in, 128), dev) if keep_ga else None
         gw_w = _empty((G, 128), dev) if want_gw else None
         gw_b = _empty((G, 128), dev) if want_gw else None
-        ws = L.workspace(int(L.lib.dd3d_arp_bwd_ws_bytes(M_in, G)), dev)
-        L.call("dd3d_affine_relu_pool_bwd", L.ptr(g_pool), L.ptr(arg), L.ptr(parent), L.ptr(xhat), L.ptr(w), L.ptr(b), 1, 128, M_in, L.ptr(gro), G,
-               L.ptr(gx), L.ptr(ga), L.ptr(ga_prev), L.ptr(gw_extra), L.ptr(gw_w), L.ptr(gw_b), L.ptr(ws), ws.numel(), L.stream())
-        return gx, ga, gw_w, gw_b
+        ws = L.workspace(int(L.lib.dd3d_arp_inorm_bwd_ws_bytes(B)), dev)
+        L.call("dd3d_arp_inorm_bwd", L.ptr(g_pool), L.ptr(arg), L.ptr(parent), L.ptr(xhat), L.ptr(inv_std), L.ptr(w), L.ptr(b), 128, L.ptr(seg), B,
+               L.ptr(self.cloud_group), L.ptr(self.gco), G, L.ptr(dY), L.ptr(ga), L.ptr(ga_prev), L.ptr(gw_extra), L.ptr(gw_w), L.ptr(gw_b),
+               L.ptr(ws), ws.numel(), L.stream())
+        return dY, ga, gw_w, gw_b
 
     def _bww(self, X, Cin, dY, nbr, ld, M, gro):
         G = self.G
@@ -175,14 +174,10 @@ class _Pass:
         L.call("dd3d_sparse_linear_bwd_x", L.ptr(self.dl), L.ptr(dp.site), L.ptr(dp.seg_off), B, 128, L.ptr(self.cloud_group), L.ptr(Gsm), sst, J,
                0, L.ptr(H), st)
         L.call("dd3d_sparse_linear_bwd_x", L.ptr(dz), L.ptr(dp.site), L.ptr(dp.seg_off), B, 128, None, L.ptr(self.Wsm), sst, J, 1, L.ptr(H), st)
-        hx1, _, _, _ = self._arp_bwd(H, self.arg1, cm.parent(4), self.xh1, w5, b5, gro2, M1, False, False, self.ga1, G_w5)
-        hY1 = _empty((M1, 128), dev)
-        L.call("dd3d_inorm_bwd", L.ptr(hx1), L.ptr(self.xh1), L.ptr(self.is1), L.ptr(seg2), B, 128, L.ptr(hY1), st)
+        hY1, _, _, _ = self._arp_inorm_bwd(H, self.arg1, cm.parent(4), self.xh1, self.is1, w5, b5, seg2, M1, False, False, self.ga1, G_w5)
         hP0 = _empty((M1, 128), dev)
         L.call("dd3d_conv_bwd_data", L.ptr(hY1), M1, self.cnt[1], 128, L.ptr(self.W1t), 128, L.ptr(k1), ld1, 27, L.ptr(hP0), st)
-        hx0, _, _, _ = self._arp_bwd(hP0, self.arg0, cm.parent(2), self.xh0, w1, b1, gro1, M0, False, False, self.ga0, G_w1)
-        hY0 = _empty((M0, 128), dev)
-        L.call("dd3d_inorm_bwd", L.ptr(hx0), L.ptr(self.xh0), L.ptr(self.is0), L.ptr(seg1), B, 128, L.ptr(hY0), st)
+        hY0, _, _, _ = self._arp_inorm_bwd(hP0, self.arg0, cm.parent(2), self.xh0, self.is0, w1, b1, seg1, M0, False, False, self.ga0, G_w1)
         hF0 = _empty((M0, 3), dev)
         L.call("dd3d_conv_bwd_data", L.ptr(hY0), M0, self.cnt[0], 128, L.ptr(W0), 3, L.ptr(k0), ld0, 27, L.ptr(hF0), st)
         dfeats = _empty((self.N, 3), dev)
@@ -354,6 +349,8 @@ class FusedDistiller:
         site_major(net.classifier.weight, 128, net.dense_extent[0] * net.dense_extent[1] * net.dense_extent[2])
         transposed_kernel(net.features[4].kernel)
         sr, ss = self.stream_real, self.stream_syn
+        if os.environ.get("DD3D_SINGLE_STREAM"):    # experiment switch: both passes on the main stream
+            sr = ss = main
         sr.wait_stream(main)
         ss.wait_stream(main)
         if not static:

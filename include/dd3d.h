@@ -137,6 +137,15 @@ int64_t dd3d_arp_bwd_ws_bytes(int64_t M_in, int G);
 int dd3d_affine_relu_pool_bwd(const float* g_pool, const int32_t* arg, const int32_t* parent, const float* xhat, const float* w, const float* b,
                               int use_affine_relu, int C, int64_t M_in, const int32_t* group_row_off, int G, float* g_xhat, float* ga_out,
                               const float* ga_prev, const float* gw_extra, float* gw_w, float* gw_b, void* ws, int64_t ws_bytes, void* stream);
+/* affine_relu_pool_bwd followed by inorm_bwd fused into one pass per cloud (the gradient w.r.t. xhat never goes through HBM):
+ * dY[M_in,128] is the gradient w.r.t. the instance norm's INPUT.  cloud_group[B] nullable (one group); group_cloud_off[G+1]
+ * needed when gw_w/gw_b are requested.  Same nullable pairs as dd3d_affine_relu_pool_bwd.  use_affine_relu is implied (w, b given).
+ * replaces: backward of ME.MinkowskiInstanceNorm + MinkowskiReLU + MinkowskiMaxPooling, models/MEConv.py:225-227 */
+int64_t dd3d_arp_inorm_bwd_ws_bytes(int B);
+int dd3d_arp_inorm_bwd(const float* g_pool, const int32_t* arg, const int32_t* parent, const float* xhat, const float* inv_std, const float* w,
+                       const float* b, int C, const int32_t* seg_off, int B, const int32_t* cloud_group, const int32_t* group_cloud_off, int G,
+                       float* dY, float* ga_out, const float* ga_prev, const float* gw_extra, float* gw_w, float* gw_b, void* ws, int64_t ws_bytes,
+                       void* stream);
 int dd3d_scale_rows_by_group(const float* ga, const float* gw, const int32_t* group_row_off, int G, int64_t M, int C, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------------
