@@ -1,0 +1,431 @@
+// Cloud-local coordinate maps: the whole pyramid behind MEConvExp.forward (models/MEConv.py:247,224,227,250-254) in three launches.
+//
+// Every key of the voxel hash starts with the batch index, so duplicates, kernel-map neighbours and pooling children of a voxel
+// all live in the voxel's own cloud.  A workgroup therefore takes ONE cloud, keeps its coordinates and three small hash tables
+// (tensor strides 1, 2, 4) in LDS and produces, without a single global random access:
+//   quantise (floor) -> unique (first occurrence) -> inverse map + voxel->points CSR        [TensorField.sparse()]
+//   k=3 kernel maps at strides 1 and 2                                                    [MinkowskiConvolution x2]
+//   stride-2 coordinate maps 1->2 and 2->4 with their k=2 pooling maps and parent rows    [MinkowskiMaxPooling x2]
+//   per-cloud row ranges at the three strides and the dense() placement of the last one   [SparseTensor.dense()]
+// Pass A counts the voxels of every cloud at the three strides (and folds the per-group minimum corner), one scan turns the counts
+// into row ranges, pass B rebuilds the same tables (deterministic) and emits everything at its global row.  The results are
+// bit-identical to the generic global-hash path in coords.hip (tests/test_gpu_ops.py), which stays for clouds that do not fit in LDS.
+#include "common.h"
+
+namespace {
+
+constexpr int CT = 256;  // threads per cloud
+
+template <int NMAX>
+struct CloudSmem {
+    static constexpr int HC = 2 * NMAX;  // table capacity: load factor <= 0.5, so every probe sequence meets an empty slot
+    int4 q[NMAX];                        // floored point coordinates
+    int4 U1[NMAX], U2[NMAX], U4[NMAX];   // unique coordinates at strides 1, 2, 4 (first-occurrence order)
+    int tab1[HC], tab2[HC], tab4[HC];    // coordinate -> local voxel id, linear probing, -1 = empty
+    int tmin[HC];                        // scratch: minimum key index per slot while a table is being built
+    int slot[NMAX];                      // scratch: slot of every key of the table being built
+    int lid1[NMAX];                      // point -> local voxel id (stride 1)
+    int par2[NMAX], par4[NMAX];          // stride-1 voxel -> stride-2 voxel ; stride-2 voxel -> stride-4 voxel (local ids)
+    int first1[NMAX];                    // stride-1 voxel -> its first point (local index)
+    int first2[NMAX], first4[NMAX];      // stride-2 voxel -> its first stride-1 voxel ; stride-4 voxel -> its first stride-2 voxel
+    int cnt[NMAX + 1];                   // CSR scratch
+    int s_w[8];
+};
+
+__device__ __forceinline__ int4 stride_coord(int4 c, int s) {
+    return make_int4(c.x, floor_div_i(c.y, s) * s, floor_div_i(c.z, s) * s, floor_div_i(c.w, s) * s);
+}
+
+// exclusive prefix of `v` over the 256 threads of the block (4 waves); *total = block sum.  s_w needs 4 ints.
+__device__ __forceinline__ int block_scan(int v, int* total, int* s_w) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    __syncthreads();  // s_w may still be read by the previous call
+    if (lane == 63) s_w[w] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int x = s_w[i];
+        if (i < w) base += x;
+        tot += x;
+    }
+    *total = tot;
+    return base + incl - v;
+}
+
+// Unique keys[0..n) in first-occurrence order -> U[0..count); tab maps a coordinate to its index in U afterwards;
+// lid[i] = index in U of keys[i]; first_idx[r] (nullable) = smallest i with keys[i] == U[r].  Returns count (block-uniform).
+template <int HC>
+__device__ int lds_unique(const int4* keys, int n, int* tab, int* tmin, int* slot, int4* U, int* lid, int* first_idx, int* s_w) {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < HC; i += CT) {
+        tab[i] = -1;
+        tmin[i] = 0x7FFFFFFF;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += CT) {
+        const int4 key = keys[i];
+        uint32_t h = hash_coord(key) & (HC - 1);
+        for (;;) {
+            int old = atomicCAS(&tab[h], -1, i);
+            if (old == -1 || coord_eq(keys[old], key)) break;
+            h = (h + 1) & (HC - 1);
+        }
+        slot[i] = (int)h;
+        atomicMin(&tmin[h], i);  // winner among duplicates = first occurrence
+    }
+    __syncthreads();
+    int base = 0;
+    for (int c0 = 0; c0 < n; c0 += CT) {  // stable compaction of the winners, 256 keys at a time
+        const int i = c0 + tid;
+        const bool first = i < n && tmin[slot[i]] == i;
+        int tot;
+        const int ex = block_scan(first ? 1 : 0, &tot, s_w);
+        if (first) {
+            const int r = base + ex;
+            U[r] = keys[i];
+            if (first_idx) first_idx[r] = i;
+            tab[slot[i]] = r;  // all inserts are done: the slot now holds the voxel id, keys live in U
+        }
+        base += tot;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += CT) lid[i] = tab[slot[i]];
+    __syncthreads();
+    return base;
+}
+
+template <int HC>
+__device__ __forceinline__ int lds_lookup(const int* tab, const int4* U, int4 key) {
+    uint32_t h = hash_coord(key) & (HC - 1);
+    for (;;) {
+        const int r = tab[h];
+        if (r < 0) return -1;
+        if (coord_eq(U[r], key)) return r;
+        h = (h + 1) & (HC - 1);
+    }
+}
+
+struct CloudCounts {
+    int m1, m2, m4;
+};
+
+// load + floor the cloud's points, then the three unique levels.  Sets *err |= 1 if a point's batch column is not b,
+// |= 8 if the cloud has more than NMAX points (it is truncated: results are then meaningless but nothing goes out of bounds).
+template <int NMAX>
+__device__ CloudCounts build_cloud(CloudSmem<NMAX>& S, const float4* __restrict__ coords, int p0, int n_raw, int b, int* err, int* n_out) {
+    constexpr int HC = CloudSmem<NMAX>::HC;
+    const int tid = threadIdx.x;
+    int n = n_raw;
+    if (n > NMAX) {
+        n = NMAX;
+        if (tid == 0) atomicOr(err, 8);
+    }
+    bool bad = false;
+    for (int i = tid; i < n; i += CT) {
+        const float4 c = coords[p0 + i];
+        const int4 k = make_int4((int)floorf(c.x), (int)floorf(c.y), (int)floorf(c.z), (int)floorf(c.w));
+        bad |= k.x != b;
+        S.q[i] = k;
+    }
+    if (bad) atomicOr(err, 1);
+    __syncthreads();
+    CloudCounts c;
+    c.m1 = lds_unique<HC>(S.q, n, S.tab1, S.tmin, S.slot, S.U1, S.lid1, S.first1, S.s_w);
+    // stride 2: keys = stride-2 coordinate of every stride-1 voxel (q is free again and serves as key storage)
+    for (int v = tid; v < c.m1; v += CT) S.q[v] = stride_coord(S.U1[v], 2);
+    __syncthreads();
+    c.m2 = lds_unique<HC>(S.q, c.m1, S.tab2, S.tmin, S.slot, S.U2, S.par2, S.first2, S.s_w);
+    for (int v = tid; v < c.m2; v += CT) S.q[v] = stride_coord(S.U2[v], 4);
+    __syncthreads();
+    c.m4 = lds_unique<HC>(S.q, c.m2, S.tab4, S.tmin, S.slot, S.U4, S.par4, S.first4, S.s_w);
+    *n_out = n;
+    return c;
+}
+
+// ---- pass A: voxel counts of every cloud at strides 1, 2, 4 + per-group minimum corner of the stride-4 coordinates ----
+template <int NMAX>
+__global__ __launch_bounds__(CT) void k_cloud_count(const float4* __restrict__ coords, const int* __restrict__ pt_off, int B,
+                                                    const int* __restrict__ cloud_group, int* __restrict__ cnt /*[3][B]*/, int* gmin /*[G][3]*/,
+                                                    int* err) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    CloudSmem<NMAX>& S = *reinterpret_cast<CloudSmem<NMAX>*>(smem_raw);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int p0 = pt_off[b];
+    int n;
+    const CloudCounts c = build_cloud<NMAX>(S, coords, p0, pt_off[b + 1] - p0, b, err, &n);
+    if (tid == 0) {
+        cnt[b] = c.m1;
+        cnt[B + b] = c.m2;
+        cnt[2 * B + b] = c.m4;
+    }
+    if (gmin) {
+        const int big = 0x7F7F7F7F;
+        int a = big, d = big, e = big;
+        for (int t = tid; t < c.m4; t += CT) {
+            const int4 u = S.U4[t];
+            a = min(a, u.y); d = min(d, u.z); e = min(e, u.w);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            a = min(a, __shfl_xor(a, o, 64));
+            d = min(d, __shfl_xor(d, o, 64));
+            e = min(e, __shfl_xor(e, o, 64));
+        }
+        if ((tid & 63) == 0 && a != big) {
+            const int g = cloud_group ? cloud_group[b] : 0;
+            atomicMin(&gmin[g * 3 + 0], a);
+            atomicMin(&gmin[g * 3 + 1], d);
+            atomicMin(&gmin[g * 3 + 2], e);
+        }
+    }
+}
+
+// ---- scan: seg[l][0..B] = exclusive prefix of cnt[l][0..B), counts[l] = total, for the three levels (one block) ----
+__global__ void k_cloud_scan(const int* __restrict__ cnt, int B, int* __restrict__ seg /*[3][B+1]*/, int* __restrict__ counts /*[3]*/) {
+    __shared__ int s_w[16];
+    __shared__ int s_carry;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int l = 0; l < 3; ++l) {
+        if (threadIdx.x == 0) s_carry = 0;
+        __syncthreads();
+        for (int base = 0; base < B; base += 1024) {
+            const int i = base + threadIdx.x;
+            const int v = i < B ? cnt[l * B + i] : 0;
+            int incl = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                int t = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += t;
+            }
+            if (lane == 63) s_w[w] = incl;
+            __syncthreads();
+            int wbase = 0, tot = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                int x = s_w[j];
+                if (j < w) wbase += x;
+                tot += x;
+            }
+            const int carry = s_carry;
+            if (i < B) seg[l * (B + 1) + i] = carry + wbase + incl - v;
+            __syncthreads();
+            if (threadIdx.x == 0) s_carry = carry + tot;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            seg[l * (B + 1) + B] = s_carry;
+            counts[l] = s_carry;
+        }
+        __syncthreads();
+    }
+}
+
+struct CloudOut {
+    int4 *C1, *C2, *C4;            // [bound,4] coordinates per stride
+    int *inv1, *uidx1;             // [N] point -> stride-1 row ; [bound] stride-1 row -> first point
+    int *vox_off, *vox_pts;        // [bound+1], [N]: points of every stride-1 voxel, ascending
+    int *par2, *uidx2;             // [bound] stride-1 row -> stride-2 row ; stride-2 row -> first stride-1 row
+    int *par4, *uidx4;             // [bound] stride-2 row -> stride-4 row ; stride-4 row -> first stride-2 row
+    int *nbr1, *nbr2;              // [27][ld] k=3 kernel maps at strides 1 and 2
+    int *kid2, *kid4;              // [8][ld] k=2 pooling maps 1->2 and 2->4
+    int *site, *vox_at;            // dense placement of stride 4: [bound], [S][B] (nullable pair)
+    const int* gmin;               // [G][3]
+    int64_t ld;
+    int E0, E1, E2;
+};
+
+__device__ __forceinline__ void k3_offset(int k, int ts, int* d0, int* d1, int* d2) {
+    *d0 = (k % 3 - 1) * ts;
+    *d1 = ((k / 3) % 3 - 1) * ts;
+    *d2 = (k / 9 - 1) * ts;
+}
+
+// ---- pass B: rebuild the tables and emit every map at its global rows ----
+template <int NMAX>
+__global__ __launch_bounds__(CT) void k_cloud_emit(const float4* __restrict__ coords, const int* __restrict__ pt_off, int B,
+                                                   const int* __restrict__ cloud_group, const int* __restrict__ seg /*[3][B+1]*/, CloudOut o,
+                                                   int* err) {
+    constexpr int HC = CloudSmem<NMAX>::HC;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    CloudSmem<NMAX>& S = *reinterpret_cast<CloudSmem<NMAX>*>(smem_raw);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int p0 = pt_off[b];
+    int n;
+    const CloudCounts c = build_cloud<NMAX>(S, coords, p0, pt_off[b + 1] - p0, b, err, &n);
+    const int r1 = seg[b], r2 = seg[(B + 1) + b], r4 = seg[2 * (B + 1) + b];
+
+    // stride 1: coordinates, first point, inverse map
+    for (int v = tid; v < c.m1; v += CT) {
+        o.C1[r1 + v] = S.U1[v];
+        o.uidx1[r1 + v] = p0 + S.first1[v];
+        o.par2[r1 + v] = r2 + S.par2[v];
+    }
+    for (int i = tid; i < n; i += CT) o.inv1[p0 + i] = r1 + S.lid1[i];
+    // voxel -> points CSR (local counting sort; the tiny lists are put in ascending point order afterwards)
+    for (int v = tid; v <= c.m1; v += CT) S.cnt[v] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += CT) atomicAdd(&S.cnt[S.lid1[i]], 1);
+    __syncthreads();
+    {   // exclusive scan of cnt[0..m1) in place, 256 at a time; S.slot becomes the write cursor
+        int carry = 0;
+        for (int c0 = 0; c0 < c.m1; c0 += CT) {
+            const int v = c0 + tid;
+            const int x = v < c.m1 ? S.cnt[v] : 0;
+            int tot;
+            const int ex = block_scan(x, &tot, S.s_w);
+            if (v < c.m1) {
+                S.cnt[v] = carry + ex;
+                S.slot[v] = 0;
+            }
+            carry += tot;
+        }
+        if (tid == 0) S.cnt[c.m1] = carry;
+    }
+    __syncthreads();
+    for (int v = tid; v < c.m1; v += CT) o.vox_off[r1 + v] = p0 + S.cnt[v];
+    if (tid == 0) o.vox_off[r1 + c.m1] = p0 + n;  // = the next cloud's first entry; the last cloud closes the array
+    int* lpts = reinterpret_cast<int*>(S.q);       // q is free: local point lists
+    for (int i = tid; i < n; i += CT) {
+        const int v = S.lid1[i];
+        lpts[S.cnt[v] + atomicAdd(&S.slot[v], 1)] = i;
+    }
+    __syncthreads();
+    for (int v = tid; v < c.m1; v += CT) {
+        const int a = S.cnt[v], e = S.cnt[v + 1];
+        for (int i = a + 1; i < e; ++i) {
+            int x = lpts[i], j = i - 1;
+            while (j >= a && lpts[j] > x) {
+                lpts[j + 1] = lpts[j];
+                --j;
+            }
+            lpts[j + 1] = x;
+        }
+        for (int i = a; i < e; ++i) o.vox_pts[p0 + i] = p0 + lpts[i];
+    }
+    // stride 2 and 4: coordinates, parents, first rows
+    for (int u = tid; u < c.m2; u += CT) {
+        o.C2[r2 + u] = S.U2[u];
+        o.par4[r2 + u] = r4 + S.par4[u];
+        o.uidx2[r2 + u] = r1 + S.first2[u];
+    }
+    for (int t = tid; t < c.m4; t += CT) {
+        o.C4[r4 + t] = S.U4[t];
+        o.uidx4[r4 + t] = r2 + S.first4[t];
+    }
+
+    // k=3 kernel maps: one (offset, voxel) probe per thread iteration, writes coalesced along the voxel index
+    for (int idx = tid; idx < 27 * c.m1; idx += CT) {
+        const int k = idx / c.m1, v = idx - k * c.m1;
+        int d0, d1, d2;
+        k3_offset(k, 1, &d0, &d1, &d2);
+        const int4 u = S.U1[v];
+        const int r = lds_lookup<HC>(S.tab1, S.U1, make_int4(u.x, u.y + d0, u.z + d1, u.w + d2));
+        o.nbr1[(int64_t)k * o.ld + r1 + v] = r < 0 ? -1 : r1 + r;
+    }
+    for (int idx = tid; idx < 27 * c.m2; idx += CT) {
+        const int k = idx / c.m2, v = idx - k * c.m2;
+        int d0, d1, d2;
+        k3_offset(k, 2, &d0, &d1, &d2);
+        const int4 u = S.U2[v];
+        const int r = lds_lookup<HC>(S.tab2, S.U2, make_int4(u.x, u.y + d0, u.z + d1, u.w + d2));
+        o.nbr2[(int64_t)k * o.ld + r2 + v] = r < 0 ? -1 : r2 + r;
+    }
+    // k=2 pooling maps: children of a stride-2s voxel at offsets {0,1}*s, k = e0 + 2 e1 + 4 e2
+    for (int idx = tid; idx < 8 * c.m2; idx += CT) {
+        const int k = idx / c.m2, v = idx - k * c.m2;
+        const int4 u = S.U2[v];
+        const int r = lds_lookup<HC>(S.tab1, S.U1, make_int4(u.x, u.y + (k & 1), u.z + ((k >> 1) & 1), u.w + (k >> 2)));
+        o.kid2[(int64_t)k * o.ld + r2 + v] = r < 0 ? -1 : r1 + r;
+    }
+    for (int idx = tid; idx < 8 * c.m4; idx += CT) {
+        const int k = idx / c.m4, v = idx - k * c.m4;
+        const int4 u = S.U4[v];
+        const int r = lds_lookup<HC>(S.tab2, S.U2, make_int4(u.x, u.y + 2 * (k & 1), u.z + 2 * ((k >> 1) & 1), u.w + 2 * (k >> 2)));
+        o.kid4[(int64_t)k * o.ld + r4 + v] = r < 0 ? -1 : r2 + r;
+    }
+    // dense() placement of the stride-4 voxels: site = flat index relative to the group's minimum corner
+    if (o.site) {
+        const int g = cloud_group ? cloud_group[b] : 0;
+        const int m0 = o.gmin[g * 3 + 0], m1 = o.gmin[g * 3 + 1], m2 = o.gmin[g * 3 + 2];
+        for (int t = tid; t < c.m4; t += CT) {
+            const int4 u = S.U4[t];
+            const int a = (u.y - m0) / 4, d = (u.z - m1) / 4, e = (u.w - m2) / 4;
+            if (a < 0 || a >= o.E0 || d < 0 || d >= o.E1 || e < 0 || e >= o.E2) {
+                atomicOr(err, 2);  // MinkowskiEngine's dense() raises here
+                o.site[r4 + t] = -1;
+            } else {
+                const int s = (a * o.E1 + d) * o.E2 + e;
+                o.site[r4 + t] = s;
+                if (o.vox_at) o.vox_at[(int64_t)s * B + b] = r4 + t;
+            }
+        }
+    }
+}
+
+template <int NMAX>
+int launch_cloud_maps(const float4* coords, const int* pt_off, int B, const int* cloud_group, int* cnt, int* seg, int* counts, const CloudOut& o,
+                      int* gmin, int* err, hipStream_t st) {
+    const size_t smem = sizeof(CloudSmem<NMAX>);
+    if (smem > 64 * 1024) {
+        DD3D_HIP(hipFuncSetAttribute((const void*)k_cloud_count<NMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        DD3D_HIP(hipFuncSetAttribute((const void*)k_cloud_emit<NMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    }
+    k_cloud_count<NMAX><<<dim3(B), CT, smem, st>>>(coords, pt_off, B, cloud_group, cnt, gmin, err);
+    k_cloud_scan<<<1, 1024, 0, st>>>(cnt, B, seg, counts);
+    k_cloud_emit<NMAX><<<dim3(B), CT, smem, st>>>(coords, pt_off, B, cloud_group, seg, o, err);
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+DD3D_API int dd3d_cloud_maps_max_points(void) { return 1024; }
+
+DD3D_API int64_t dd3d_cloud_maps_ws_bytes(int B) { return align_up64((int64_t)(B > 0 ? B : 1) * 3 * 4, 256); }
+
+// See include/dd3d.h.  All outputs are sized by `bound` (>= number of points); rows beyond the counts are not written.
+DD3D_API int dd3d_cloud_maps(const float* coords, const int32_t* pt_off, int B, int max_points, int64_t bound, const int32_t* cloud_group, int G,
+                             int E0, int E1, int E2, int32_t* counts /*[3]*/, int32_t* seg /*[3][B+1]*/, int32_t* C1, int32_t* C2, int32_t* C4,
+                             int32_t* inv1, int32_t* uidx1, int32_t* vox_off, int32_t* vox_pts, int32_t* par2, int32_t* uidx2, int32_t* par4,
+                             int32_t* uidx4, int32_t* nbr1, int32_t* nbr2, int32_t* kid2, int32_t* kid4, int64_t ld, int32_t* gmin, int32_t* site,
+                             int32_t* vox_at, int32_t* err_dev, void* ws, int64_t ws_bytes, void* stream) {
+    if (B < 0 || max_points <= 0 || max_points > dd3d_cloud_maps_max_points() || bound < 0 || ld < bound || G <= 0 || !counts || !seg || !err_dev)
+        return DD3D_EARG;
+    if (bound >= (1ll << 31) / 32) return DD3D_ESIZE;
+    if (ws_bytes < dd3d_cloud_maps_ws_bytes(B) || !ws) return DD3D_EWS;
+    const bool dense = site != nullptr;
+    if (dense && (!gmin || E0 <= 0 || E1 <= 0 || E2 <= 0)) return DD3D_EARG;
+    if (vox_at && !dense) return DD3D_EARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (dense) {
+        DD3D_HIP(hipMemsetAsync(gmin, 0x7F, (size_t)G * 3 * 4, st));
+        if (vox_at && B > 0) DD3D_HIP(hipMemsetAsync(vox_at, 0xFF, (size_t)B * E0 * E1 * E2 * 4, st));
+    }
+    if (B == 0) {
+        DD3D_HIP(hipMemsetAsync(counts, 0, 12, st));
+        DD3D_HIP(hipMemsetAsync(seg, 0, 12, st));
+        if (vox_off) DD3D_HIP(hipMemsetAsync(vox_off, 0, 4, st));
+        return 0;
+    }
+    if (!coords || !pt_off || !C1 || !C2 || !C4 || !inv1 || !uidx1 || !vox_off || !vox_pts || !par2 || !uidx2 || !par4 || !uidx4 || !nbr1 || !nbr2 ||
+        !kid2 || !kid4)
+        return DD3D_EARG;
+    CloudOut o;
+    o.C1 = (int4*)C1; o.C2 = (int4*)C2; o.C4 = (int4*)C4;
+    o.inv1 = inv1; o.uidx1 = uidx1; o.vox_off = vox_off; o.vox_pts = vox_pts;
+    o.par2 = par2; o.uidx2 = uidx2; o.par4 = par4; o.uidx4 = uidx4;
+    o.nbr1 = nbr1; o.nbr2 = nbr2; o.kid2 = kid2; o.kid4 = kid4;
+    o.site = site; o.vox_at = vox_at; o.gmin = gmin;
+    o.ld = ld; o.E0 = E0; o.E1 = E1; o.E2 = E2;
+    int* cnt = (int*)ws;
+    if (max_points <= 256)
+        return launch_cloud_maps<256>((const float4*)coords, pt_off, B, cloud_group, cnt, seg, counts, o, dense ? gmin : nullptr, err_dev, st);
+    return launch_cloud_maps<1024>((const float4*)coords, pt_off, B, cloud_group, cnt, seg, counts, o, dense ? gmin : nullptr, err_dev, st);
+}

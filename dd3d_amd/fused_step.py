@@ -26,7 +26,7 @@ import torch
 from . import _lib as L
 from .distillation_loss import _METRICS, _rows_cols
 from .ops import DensePlacement, _site_strides, transposed_kernel
-from .sparse import CoordinateManager
+from .sparse import CloudCoordinateManager, CoordinateManager
 from .utils.Mnist2D import batch_from_images
 
 _F32, _I32 = torch.float32, torch.int32
@@ -39,7 +39,7 @@ def _empty(shape, dev, dtype=_F32):
 class _Pass:
     """Forward + first-order backward of MEConvExp over one class-batched set of clouds; keeps what the second-order pass needs."""
 
-    def __init__(self, net, coords, B, G, cloud_group, group_cloud_off, n_dev=None, static=False):
+    def __init__(self, net, coords, B, G, cloud_group, group_cloud_off, n_dev=None, static=False, pt_off=None, max_points=0):
         """Phase 1 (no host sync): every coordinate map of the pass, enqueued on the current stream.
         ``static``: never read a size back -- every launch covers its bound and takes the true row count from the device
         (``n_dev`` = number of valid rows of ``coords``), so the pass can be captured into a HIP graph."""
@@ -47,7 +47,12 @@ class _Pass:
         self.dev, self.B, self.G, self.net = dev, B, G, net
         self.cloud_group, self.gco = cloud_group, group_cloud_off
         self.static = static
-        cm = self.cm = CoordinateManager(coords, B, n_dev=n_dev)
+        if pt_off is not None and 0 < max_points <= int(L.lib.dd3d_cloud_maps_max_points()):
+            # clouds small enough for LDS: the whole pyramid (+ dense placement) in three launches
+            cm = CloudCoordinateManager(coords, pt_off, B, max_points, net.dense_extent, cloud_group, G)
+        else:
+            cm = CoordinateManager(coords, B, n_dev=n_dev)
+        self.cm = cm
         self.N = cm.N
         k0, p0 = cm.kernel_map(1, 1, 3), cm.kernel_map(1, 2, 2)
         k1, p1 = cm.kernel_map(2, 2, 3), cm.kernel_map(2, 4, 2)
@@ -243,6 +248,7 @@ class FusedDistiller:
         self.syn_labels = cls.repeat_interleave(ipc).to(_I32)
         self.syn_group = torch.arange(G, device=dev, dtype=_I32).repeat_interleave(ipc)
         self.syn_gco = (torch.arange(G + 1, device=dev) * ipc).to(_I32)
+        self.syn_pt_off = (torch.arange(G * ipc + 1, device=dev) * num_points).to(_I32)
         self.syn_batch_col = torch.arange(G * ipc, device=dev, dtype=_F32).repeat_interleave(num_points)[:, None]
         self.last = {}
         # the real and the synthetic pass are independent until the loss: they run on two streams, so the small synthetic kernels and
@@ -358,9 +364,10 @@ class FusedDistiller:
                 if torch.is_tensor(t):
                     t.record_stream(sr)
         with torch.cuda.stream(sr):
-            real = _Pass(self.network, rb["coordinates"], B_r, G, rb["cloud_group"], rb["group_cloud_off"], rb.get("n_dev"), static)
+            real = _Pass(self.network, rb["coordinates"], B_r, G, rb["cloud_group"], rb["group_cloud_off"], rb.get("n_dev"), static,
+                         rb.get("pt_off"), npts)
         with torch.cuda.stream(ss):
-            syn = _Pass(self.network, coords, G * ipc, G, self.syn_group, self.syn_gco, None, static)
+            syn = _Pass(self.network, coords, G * ipc, G, self.syn_group, self.syn_gco, None, static, self.syn_pt_off, npts)
         with torch.cuda.stream(sr):
             real.run(rb["features"], rb["labels"], False)
         with torch.cuda.stream(ss):
@@ -389,7 +396,7 @@ class FusedDistiller:
         L.call("dd3d_gather_clouds", L.ptr(st.pool_xyz), L.ptr(st.pool_off), st.n_pool, L.ptr(st.ids), st.B, self.num_points, st.bound,
                L.ptr(st.coords), L.ptr(st.feats), L.ptr(st.pt_off), L.ptr(st.n), L.ptr(st.err), L.stream())
         rb = {"coordinates": st.coords, "features": st.feats, "labels": st.labels, "num_clouds": st.B, "cloud_group": st.cloud_group,
-              "group_cloud_off": st.gco, "n_dev": st.n}
+              "group_cloud_off": st.gco, "n_dev": st.n, "pt_off": st.pt_off}
         with L.ws_scope(self._scope):
             return self._compute(rb, True)
 

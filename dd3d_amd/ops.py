@@ -245,13 +245,17 @@ class DensePlacement:
         self.B, self.G = cm.B, G
         self.E = tuple(int(e) for e in extent)
         self.S = self.E[0] * self.E[1] * self.E[2]
+        self.cloud_group = cloud_group
+        self.group_cloud_off = group_cloud_off if group_cloud_off is not None else torch.tensor([0, self.B], dtype=torch.int32, device=dev)
+        self.seg_off = cm.seg_off(stride)
+        pre = getattr(cm, "dense_tables", None)
+        if pre is not None and stride == 4 and pre[0] == self.E and pre[1] is cloud_group:
+            _, _, self.gmin, self.site, self.vox_at = pre     # the cloud-local map builder already placed the voxels
+            return
         bound = cm._rows_bound(lv)
         self.site = torch.empty(max(bound, 1), dtype=torch.int32, device=dev)
         self.vox_at = torch.empty((self.S, max(self.B, 1)), dtype=torch.int32, device=dev)
         self.gmin = torch.empty((G, 3), dtype=torch.int32, device=dev)
-        self.cloud_group = cloud_group
-        self.group_cloud_off = group_cloud_off if group_cloud_off is not None else torch.tensor([0, self.B], dtype=torch.int32, device=dev)
-        self.seg_off = cm.seg_off(stride)
         L.call("dd3d_dense_sites", L.ptr(lv.C), cm._count_ptr(lv), bound, L.ptr(cloud_group), G, self.B, stride, self.E[0], self.E[1], self.E[2],
                L.ptr(self.gmin), L.ptr(self.site), L.ptr(self.vox_at), L.ptr(cm.err), L.stream())
         cm._synced = False

@@ -195,6 +195,68 @@ class CoordinateManager:
         return in_rows[:P], out_rows[:P], offs
 
 
+class CloudCoordinateManager(CoordinateManager):
+    """The coordinate pyramid of MEConvExp (tensor strides 1, 2, 4; both k=3 kernel maps; both stride-2 pooling maps; per-cloud row
+    ranges; optionally the dense() placement of stride 4) from ``dd3d_cloud_maps``: three launches, one workgroup per cloud, all
+    hashing in LDS.  Needs the first point of every cloud (``pt_off`` int32[B+1] on the device; ``pt_off[B]`` = number of points, the
+    rest of ``coords`` is ignored) and at most ``dd3d_cloud_maps_max_points()`` points per cloud.  Everything it produces is
+    bit-identical to what ``CoordinateManager`` builds call by call; other strides / kernel sizes are not available here."""
+
+    def __init__(self, coords: torch.Tensor, pt_off: torch.Tensor, num_clouds: int, max_points: int, dense_extent=None,
+                 cloud_group: Optional[torch.Tensor] = None, num_groups: int = 1):
+        if coords.dim() != 2 or coords.shape[1] != 4:
+            raise ValueError("coordinates must be [N,4] = (batch, c1, c2, c3)")
+        coords = coords.detach().to(torch.float32).contiguous()
+        if not coords.is_cuda:
+            raise RuntimeError("dd3d_amd has no CPU path: coordinates must live on the GPU")
+        if max_points > int(L.lib.dd3d_cloud_maps_max_points()):
+            raise ValueError("clouds too large for the LDS map builder; use CoordinateManager")
+        dev = self.device = coords.device
+        self.N = int(coords.shape[0])
+        self.coords, self._B, self.n_dev = coords, int(num_clouds), pt_off[num_clouds:]
+        self.counts = torch.zeros(self.MAX_LEVELS, dtype=_I32, device=dev)
+        self.err = torch.zeros(1, dtype=_I32, device=dev)
+        self.levels, self.kmaps, self._synced = {}, {}, False
+        B, bound = self._B, max(self.N, 1)
+        i32 = lambda *shape: torch.empty(shape, dtype=_I32, device=dev)
+        C = [i32(bound, 4) for _ in range(3)]
+        inv1, uidx1, par2, uidx2, par4, uidx4 = (i32(bound) for _ in range(6))
+        self.vox_off, self.vox_pts = i32(bound + 1), i32(bound)
+        nbr1, nbr2, kid2, kid4 = i32(27, bound), i32(27, bound), i32(8, bound), i32(8, bound)
+        seg = i32(3, B + 1)
+        self.dense_tables = None
+        E, gmin, site, vox_at = (0, 0, 0), None, None, None
+        if dense_extent is not None:
+            E = tuple(int(e) for e in dense_extent)
+            gmin, site, vox_at = i32(num_groups, 3), i32(bound), i32(E[0] * E[1] * E[2], max(B, 1))
+            self.dense_tables = (E, cloud_group, gmin, site, vox_at)
+        ws = L.workspace(int(L.lib.dd3d_cloud_maps_ws_bytes(B)), dev)
+        L.call("dd3d_cloud_maps", L.ptr(coords), L.ptr(pt_off), B, int(max_points), self.N, L.ptr(cloud_group), int(num_groups), E[0], E[1], E[2],
+               L.ptr(self.counts), L.ptr(seg), L.ptr(C[0]), L.ptr(C[1]), L.ptr(C[2]), L.ptr(inv1), L.ptr(uidx1), L.ptr(self.vox_off),
+               L.ptr(self.vox_pts), L.ptr(par2), L.ptr(uidx2), L.ptr(par4), L.ptr(uidx4), L.ptr(nbr1), L.ptr(nbr2), L.ptr(kid2), L.ptr(kid4), bound,
+               L.ptr(gmin), L.ptr(site), L.ptr(vox_at), L.ptr(self.err), L.ptr(ws), ws.numel(), L.stream())
+        for slot, (stride, inv, uidx) in enumerate(((1, inv1, uidx1), (2, par2, uidx2), (4, par4, uidx4))):
+            lv = _Level()
+            lv.stride, lv.bound, lv.slot, lv.cap, lv.table = stride, self.N, slot, 0, None
+            lv.C, lv.inv, lv.uidx, lv.seg_off = C[slot], inv, uidx, seg[slot]
+            self.levels[stride] = lv
+        self.kmaps = {(1, 1, 3): (nbr1, bound), (1, 2, 2): (kid2, bound), (2, 2, 3): (nbr2, bound), (2, 4, 2): (kid4, bound)}
+
+    def ensure_level(self, stride: int) -> _Level:
+        if stride not in self.levels:
+            raise ValueError("CloudCoordinateManager holds tensor strides 1, 2, 4 only")
+        return self.levels[stride]
+
+    def kernel_map(self, in_stride: int, out_stride: int, kernel_size: int):
+        key = (in_stride, out_stride, kernel_size)
+        if key not in self.kmaps:
+            raise ValueError("CloudCoordinateManager holds the k=3 maps at strides 1, 2 and the k=2 stride-2 pooling maps only")
+        return self.kmaps[key]
+
+    def seg_off(self, stride: int) -> torch.Tensor:
+        return self.ensure_level(stride).seg_off
+
+
 class SparseTensor:
     """Features ``F`` [M,C] on the voxels of ``coordinate_manager`` at ``tensor_stride``."""
 

@@ -71,5 +71,7 @@ def batch_from_images(images, labels, num_points=None):
     rank = torch.arange(nz.shape[0], device=nz.device) - start[b]
     nz = nz[rank < num_points]
     coords = nz.to(torch.float32)
+    kept = counts.clamp(max=num_points)
+    pt_off = torch.cat([kept.new_zeros(1), torch.cumsum(kept, 0)]).to(torch.int32)   # first point of every cloud (+ total)
     return {"coordinates": coords, "features": coords[:, 1:].clone(), "labels": labels.to(torch.int64).reshape(-1),
-            "num_clouds": B}
+            "num_clouds": B, "pt_off": pt_off}

@@ -83,6 +83,26 @@ int dd3d_dense_sites(const int32_t* C, const int32_t* m_dev, int64_t bound, cons
 int dd3d_gather_clouds(const float* pool_xyz, const int32_t* pool_off, int n_pool, const int32_t* ids, int B, int cap, int64_t bound, float* coords,
                        float* feats, int32_t* pt_off, int32_t* n_dev, int32_t* err_dev, void* stream);
 
+/* The whole coordinate pyramid of MEConvExp.forward in three launches, for batches whose clouds have at most
+ * dd3d_cloud_maps_max_points() points each: one workgroup per cloud builds the voxel hashes of tensor strides 1, 2, 4 in LDS
+ * (duplicates, neighbours and pooling children never leave a cloud because the batch index is part of every key).
+ * coords[.,4] f32 rows grouped by cloud, pt_off[B+1] = first point of every cloud (device), bound >= pt_off[B], ld >= bound.
+ * Outputs (all device, sized by bound; bit-identical to dd3d_floor_coords/unique_rows/voxel_csr/stride_coords/kernel_map/
+ * segment_offsets/dense_sites): counts[3] rows at strides 1,2,4; seg[3][B+1] per-cloud row ranges; C1,C2,C4 coordinates; inv1,
+ * uidx1, vox_off, vox_pts; par2/par4 (row at the coarser stride) and uidx2/uidx4 (first finer row); nbr1/nbr2 [27][ld] k=3 kernel
+ * maps at strides 1 and 2; kid2/kid4 [8][ld] k=2 stride-2 pooling maps; optional dense placement of stride 4 (gmin[G,3], site,
+ * vox_at[E0*E1*E2][B]; pass site = NULL to skip).  *err_dev |= 1 batch column of a point != its cloud, |= 2 voxel outside the
+ * dense extent, |= 8 a cloud has more than max_points points.
+ * replaces: x.sparse(), the coordinate maps of both MinkowskiConvolution and both MinkowskiMaxPooling layers and the index math of
+ * SparseTensor.dense(), models/MEConv.py:247,224,227,250-254 */
+int dd3d_cloud_maps_max_points(void);
+int64_t dd3d_cloud_maps_ws_bytes(int B);
+int dd3d_cloud_maps(const float* coords, const int32_t* pt_off, int B, int max_points, int64_t bound, const int32_t* cloud_group, int G, int E0,
+                    int E1, int E2, int32_t* counts, int32_t* seg, int32_t* C1, int32_t* C2, int32_t* C4, int32_t* inv1, int32_t* uidx1,
+                    int32_t* vox_off, int32_t* vox_pts, int32_t* par2, int32_t* uidx2, int32_t* par4, int32_t* uidx4, int32_t* nbr1, int32_t* nbr2,
+                    int32_t* kid2, int32_t* kid4, int64_t ld, int32_t* gmin, int32_t* site, int32_t* vox_at, int32_t* err_dev, void* ws,
+                    int64_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------------
  * (2) sparse convolution, gather-GEMM with atomic-free output (fp32 MFMA for Cin = 128)
  * ------------------------------------------------------------------------------------------------------------------- */

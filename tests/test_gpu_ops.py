@@ -321,3 +321,63 @@ def test_dense_out_of_extent_is_an_error():
     DensePlacement(cm, 4, (1, 28, 28))
     with pytest.raises(IndexError):
         cm.sync()
+
+
+@pytest.mark.parametrize("case", CASES + [dict(B=12, pts=1000, extent=20, seed=6, dims3=True, neg=True)])
+def test_cloud_local_maps_equal_generic_maps(case):
+    """dd3d_cloud_maps (one workgroup per cloud, LDS hashes, 3 launches) against the generic global-hash chain of the same library
+    (itself pinned to the oracle above): every integer output bit-identical -- coordinates, counts, inverse / first-row maps, the
+    voxel->points CSR, both k=3 kernel maps, both pooling maps, per-cloud row ranges and the dense() placement with 2 groups."""
+    from dd3d_amd.ops import DensePlacement
+    from dd3d_amd.sparse import CloudCoordinateManager
+    coords = make_coords(**case).to(dev())
+    B = case["B"]
+    # an empty cloud in the middle (and one at the end) must not disturb anything
+    coords[:, 0] += (coords[:, 0] >= B // 2).float()
+    B += 2
+    cnt = torch.bincount(coords[:, 0].long(), minlength=B)
+    pt_off = torch.cat([cnt.new_zeros(1), torch.cumsum(cnt, 0)]).to(torch.int32)
+    maxp = int(cnt.max())
+    G = 2
+    cg = (torch.arange(B, device=dev()) >= B // 3).to(torch.int32)
+    gco = torch.tensor([0, B // 3, B], dtype=torch.int32, device=dev())
+    ext = (64, 64, 64) if case.get("dims3") else (1, 64, 64)
+    ref = manager(coords, B)
+    dref = DensePlacement(ref, 4, ext, cg, G, gco)
+    # bound larger than the point count: trailing rows of `coords` are ignored
+    padded = torch.cat([coords, torch.full((37, 4), 3.0, device=dev())])
+    cm = CloudCoordinateManager(padded, pt_off, B, maxp, ext, cg, G)
+    dcm = DensePlacement(cm, 4, ext, cg, G, gco)
+    assert dcm.site is cm.dense_tables[3]
+    ref.sync()
+    cm.sync()
+    N = coords.shape[0]
+    Ms = [ref.num_rows(s) for s in (1, 2, 4)]
+    assert [cm.num_rows(s) for s in (1, 2, 4)] == Ms
+    for s, M in zip((1, 2, 4), Ms):
+        assert torch.equal(cm.coordinates(s), ref.coordinates(s))
+        assert torch.equal(cm.seg_off(s), ref.seg_off(s))
+        assert torch.equal(cm.levels[s].uidx[:M], ref.levels[s].uidx[:M])
+    assert torch.equal(cm.levels[1].inv[:N], ref.levels[1].inv[:N])
+    assert torch.equal(cm.parent(2)[:Ms[0]], ref.parent(2)[:Ms[0]]) and torch.equal(cm.parent(4)[:Ms[1]], ref.parent(4)[:Ms[1]])
+    assert torch.equal(cm.vox_off[:Ms[0] + 1], ref.vox_off[:Ms[0] + 1]) and torch.equal(cm.vox_pts[:N], ref.vox_pts[:N])
+    for (si, so, k) in ((1, 1, 3), (2, 2, 3), (1, 2, 2), (2, 4, 2)):
+        Mo = ref.num_rows(so)
+        assert torch.equal(cm.kernel_map(si, so, k)[0][:, :Mo], ref.kernel_map(si, so, k)[0][:, :Mo]), (si, so, k)
+    assert torch.equal(dcm.gmin, dref.gmin)
+    assert torch.equal(dcm.site[:Ms[2]], dref.site[:Ms[2]]) and torch.equal(dcm.vox_at, dref.vox_at)
+
+
+def test_cloud_local_maps_flag_errors():
+    from dd3d_amd.sparse import CloudCoordinateManager
+    coords = make_coords(B=3, pts=50, extent=10, seed=8).to(dev())
+    cnt = torch.bincount(coords[:, 0].long(), minlength=3)
+    pt_off = torch.cat([cnt.new_zeros(1), torch.cumsum(cnt, 0)]).to(torch.int32)
+    bad = coords.clone()
+    bad[0, 0] = 2.0                                     # a point whose batch column is not its cloud
+    with pytest.raises(RuntimeError):
+        CloudCoordinateManager(bad, pt_off, 3, 64).sync()
+    with pytest.raises(IndexError):                     # dense extent too small
+        CloudCoordinateManager(coords, pt_off, 3, 64, (1, 1, 1)).sync()
+    with pytest.raises(ValueError):
+        CloudCoordinateManager(coords, pt_off, 3, 100000)
