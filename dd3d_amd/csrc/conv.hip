@@ -300,7 +300,20 @@ __global__ __launch_bounds__(256) void k_conv3_fwd(const float* __restrict__ X, 
     const int M_out = m_dev ? min(*m_dev, M_bound) : M_bound;
     const int64_t first = (int64_t)blockIdx.x * TILES * 64;
     if (first >= M_out) return;
-    for (int i = tid; i < 96 * 128; i += 256) Ws[i] = i < K * 3 * 128 ? W[i] : 0.f;
+    {   // W -> LDS: all loads are issued before the first LDS write (a load-wait-store loop would serialise 12 L2 round trips)
+        const f32x4* W4 = (const f32x4*)W;
+        f32x4* Ws4 = (f32x4*)Ws;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        f32x4 wreg[12];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            const int idx = j * 256 + tid;
+            wreg[j] = W4[min(idx, K * 3 * 32 - 1)];
+            if (idx >= K * 3 * 32) wreg[j] = zero;
+        }
+#pragma unroll
+        for (int j = 0; j < 12; ++j) Ws4[j * 256 + tid] = wreg[j];
+    }
     for (int i = tid; i < 64 * LDA; i += 256) As[i] = 0.f;  // columns 81..96 stay zero
     const int sr = tid & 63, sk = tid >> 6;                 // staging: row of the tile, offset lane (4 lanes walk the 27 offsets)
     for (int t = 0; t < TILES; ++t) {
@@ -309,21 +322,29 @@ __global__ __launch_bounds__(256) void k_conv3_fwd(const float* __restrict__ X, 
         if (tid == 0) s_kmask = 0;
         __syncthreads();  // previous tile's MFMA reads of As are done; W / zero fill visible
         unsigned mymask = 0;
-        const int64_t row = row0 + sr;
+        const int64_t row = min(row0 + sr, (int64_t)M_out - 1);  // clamped: every load below has a valid address, no branches,
+        const bool live = row0 + sr < M_out;                     // so the 7 table loads and then the 7 gathers are all in flight
+        int nb[7];
+#pragma unroll
+        for (int kk = 0; kk < 7; ++kk) {
+            const int k = min(sk + kk * 4, K - 1);
+            nb[kk] = nbr[(int64_t)k * ld + row];
+        }
+        float xv[7][3];
+#pragma unroll
+        for (int kk = 0; kk < 7; ++kk) {
+            const float* x = X + (int64_t)max(nb[kk], 0) * 3;
+            xv[kk][0] = x[0]; xv[kk][1] = x[1]; xv[kk][2] = x[2];
+        }
 #pragma unroll
         for (int kk = 0; kk < 7; ++kk) {
             const int k = sk + kk * 4;
             if (k < K) {
-                const int nb = row < M_out ? nbr[(int64_t)k * ld + row] : -1;
-                float x0 = 0.f, x1 = 0.f, x2 = 0.f;
-                if (nb >= 0) {
-                    const float* x = X + (int64_t)nb * 3;
-                    x0 = x[0]; x1 = x[1]; x2 = x[2];
-                    mymask |= 1u << k;
-                }
-                As[sr * LDA + k * 3 + 0] = x0;
-                As[sr * LDA + k * 3 + 1] = x1;
-                As[sr * LDA + k * 3 + 2] = x2;
+                const bool ok = live && nb[kk] >= 0;
+                if (ok) mymask |= 1u << k;
+                As[sr * LDA + k * 3 + 0] = ok ? xv[kk][0] : 0.f;
+                As[sr * LDA + k * 3 + 1] = ok ? xv[kk][1] : 0.f;
+                As[sr * LDA + k * 3 + 2] = ok ? xv[kk][2] : 0.f;
             }
         }
         if (mymask) atomicOr(&s_kmask, mymask);
@@ -425,19 +446,24 @@ __global__ __launch_bounds__(256) void k_conv3_bww(const float* __restrict__ X, 
     __syncthreads();
     for (int rb = r0; rb < r1; rb += 32) {
         int row = rb + sr;
+        const int rowc = min(row, r1 - 1);  // clamped: branch-free loads, all four table reads then all four gathers in flight
+        int nb[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) nb[kk] = nbr[(int64_t)min(sk + kk * 8, 26) * ld + rowc];
+        float xv[4][3];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const float* x = X + (int64_t)max(nb[kk], 0) * 3;
+            xv[kk][0] = x[0]; xv[kk][1] = x[1]; xv[kk][2] = x[2];
+        }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             int k = sk + kk * 8;
             if (k < 27) {
-                int nb = row < r1 ? nbr[(int64_t)k * ld + row] : -1;
-                float x0 = 0.f, x1 = 0.f, x2 = 0.f;
-                if (nb >= 0) {
-                    const float* x = X + (int64_t)nb * 3;
-                    x0 = x[0]; x1 = x[1]; x2 = x[2];
-                }
-                As[sr * LDA + k * 3 + 0] = x0;
-                As[sr * LDA + k * 3 + 1] = x1;
-                As[sr * LDA + k * 3 + 2] = x2;
+                const bool ok = row < r1 && nb[kk] >= 0;
+                As[sr * LDA + k * 3 + 0] = ok ? xv[kk][0] : 0.f;
+                As[sr * LDA + k * 3 + 1] = ok ? xv[kk][1] : 0.f;
+                As[sr * LDA + k * 3 + 2] = ok ? xv[kk][2] : 0.f;
             }
         }
 #pragma unroll

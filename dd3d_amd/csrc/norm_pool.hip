@@ -92,9 +92,10 @@ __global__ __launch_bounds__(RL * 32) void k_inorm_fwd(const f32x4* __restrict__
     f32x4 v[CACHE];
     f32x4 s = zero;
 #pragma unroll
-    for (int i = 0; i < CACHE; ++i) {
+    for (int i = 0; i < CACHE; ++i) {  // clamped row index: branch-free, all CACHE loads in flight together
         int r = r0 + rl + i * RL;
-        v[i] = r < r1 ? Y[(int64_t)r * 32 + c4] : zero;
+        v[i] = Y[(int64_t)min(r, r1 - 1) * 32 + c4];
+        if (r >= r1) v[i] = zero;
         s += v[i];
     }
     for (int r = r0 + rl + CACHE * RL; r < r1; r += RL) s += Y[(int64_t)r * 32 + c4];
@@ -138,8 +139,9 @@ __global__ __launch_bounds__(RL * 32) void k_inorm_bwd(const f32x4* __restrict__
 #pragma unroll
     for (int i = 0; i < CACHE; ++i) {
         int r = r0 + rl + i * RL;
-        vg[i] = r < r1 ? g[(int64_t)r * 32 + c4] : zero;
-        vx[i] = r < r1 ? xhat[(int64_t)r * 32 + c4] : zero;
+        vg[i] = g[(int64_t)min(r, r1 - 1) * 32 + c4];
+        vx[i] = xhat[(int64_t)min(r, r1 - 1) * 32 + c4];
+        if (r >= r1) vg[i] = vx[i] = zero;
         s1 += vg[i];
         s2 += vg[i] * vx[i];
     }
@@ -179,10 +181,19 @@ __global__ __launch_bounds__(256) void k_arp_fwd(const f32x4* __restrict__ xhat,
     const float ninf = -__builtin_inff();
     f32x4 best = {ninf, ninf, ninf, ninf};
     int4 a = make_int4(-1, -1, -1, -1);
-    for (int k = 0; k < Kp; ++k) {
-        int i = kids[(int64_t)k * ld + o];
-        if (i < 0) continue;
-        f32x4 v = xhat[(int64_t)i * 32 + c4];
+    // all child indices first, then all child rows (absent children read row 0 and are masked): 8 gathers in flight instead of a
+    // serial index -> row -> compare chain per child
+    int ch[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ch[k] = kids[(int64_t)min(k, Kp - 1) * ld + o];
+    f32x4 rows[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) rows[k] = xhat[(int64_t)max(ch[k], 0) * 32 + c4];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = ch[k];
+        if (k >= Kp || i < 0) continue;
+        f32x4 v = rows[k];
         if (use_affine_relu) {
             v = v * ww + bb;
 #pragma unroll
@@ -316,19 +327,16 @@ __global__ __launch_bounds__(RL * 32) void k_arp_inorm_bwd(const f32x4* __restri
     f32x4 vg[CACHE], vx[CACHE];
     f32x4 sw = zero, sb = zero, s1 = zero, s2 = zero;
 #pragma unroll
-    for (int i = 0; i < CACHE; ++i) {
+    for (int i = 0; i < CACHE; ++i) {  // clamped row index: no branch around the loads, the CACHE rows' gathers overlap
         const int r = r0 + rl + i * RL;
-        vg[i] = zero;
-        vx[i] = zero;
-        if (r < r1) {
-            f32x4 ga;
-            row(r, vx[i], ga, vg[i]);
-            if (ga_out) ga_out[(int64_t)r * 32 + c4] = ga;
-            sw += ga * vx[i];
-            sb += ga;
-            s1 += vg[i];
-            s2 += vg[i] * vx[i];
-        }
+        f32x4 ga;
+        row(min(r, r1 - 1), vx[i], ga, vg[i]);
+        if (r >= r1) ga = vg[i] = vx[i] = zero;
+        if (ga_out && r < r1) ga_out[(int64_t)r * 32 + c4] = ga;
+        sw += ga * vx[i];
+        sb += ga;
+        s1 += vg[i];
+        s2 += vg[i] * vx[i];
     }
     for (int r = r0 + rl + CACHE * RL; r < r1; r += RL) {
         f32x4 xh, ga, gx;
@@ -362,18 +370,21 @@ __global__ __launch_bounds__(RL * 32) void k_arp_inorm_bwd(const f32x4* __restri
     }
 }
 
-// out_w/out_b[g][c4] = sum over the clouds of group g of part[b][0/1][c4]; 4 cloud-lanes take clouds in order, combined in lane order
-__global__ __launch_bounds__(256) void k_cloud_group_sum(const f32x4* __restrict__ part, const int* __restrict__ group_cloud_off, f32x4* __restrict__ gw_w,
-                                                         f32x4* __restrict__ gw_b) {
-    __shared__ f32x4 s_red[256];
+// out_w/out_b[g][c4] = sum over the clouds of group g of part[b][0/1][c4]; 16 cloud-lanes take clouds in order (a short dependent
+// chain of L2 reads each), combined in lane order: deterministic
+__global__ __launch_bounds__(1024) void k_cloud_group_sum(const f32x4* __restrict__ part, const int* __restrict__ group_cloud_off, f32x4* __restrict__ gw_w,
+                                                          f32x4* __restrict__ gw_b) {
+    __shared__ f32x4 s_red[1024];
     const int g = blockIdx.x, c4 = threadIdx.x & 31, j = (threadIdx.x >> 5) & 1, sl = threadIdx.x >> 6;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int b = group_cloud_off[g] + sl; b < group_cloud_off[g + 1]; b += 4) s += part[((int64_t)b * 2 + j) * 32 + c4];
+    for (int b = group_cloud_off[g] + sl; b < group_cloud_off[g + 1]; b += 16) s += part[((int64_t)b * 2 + j) * 32 + c4];
     s_red[threadIdx.x] = s;
     __syncthreads();
     if (sl == 0) {
-        const int t = threadIdx.x;
-        (j == 0 ? gw_w : gw_b)[(int64_t)g * 32 + c4] = s_red[t] + s_red[t + 64] + s_red[t + 128] + s_red[t + 192];
+        f32x4 t = s_red[threadIdx.x];
+#pragma unroll 4
+        for (int q = 1; q < 16; ++q) t += s_red[threadIdx.x + 64 * q];
+        (j == 0 ? gw_w : gw_b)[(int64_t)g * 32 + c4] = t;
     }
 }
 
@@ -431,7 +442,7 @@ DD3D_API int dd3d_inorm_bwd(const float* g, const float* xhat, const float* inv_
 // out[M_out,128], arg[M_out,128] (child row that won).  w/b may be null with use_affine_relu = 0 (plain max-pool).
 DD3D_API int dd3d_affine_relu_pool_fwd(const float* xhat, const float* w, const float* b, int use_affine_relu, int C, const int32_t* kids, int64_t ld,
                                        int Kp, int64_t M_out, const int32_t* m_dev, float* out, int32_t* arg, void* stream) {
-    if (M_out < 0 || C != 128 || Kp <= 0 || ld < M_out || (use_affine_relu && (!w || !b))) return DD3D_EARG;
+    if (M_out < 0 || C != 128 || Kp <= 0 || Kp > 8 || ld < M_out || (use_affine_relu && (!w || !b))) return DD3D_EARG;
     if (M_out == 0) return 0;
     if (!xhat || !kids || !out || !arg) return DD3D_EARG;
     k_arp_fwd<<<dim3((unsigned)ceil_div64(M_out, 8)), 256, 0, (hipStream_t)stream>>>((const f32x4*)xhat, (const f32x4*)w, (const f32x4*)b, use_affine_relu,
@@ -500,7 +511,7 @@ DD3D_API int dd3d_arp_inorm_bwd(const float* g_pool, const int32_t* arg, const i
                                                         (const f32x4*)w, (const f32x4*)b, seg_off, cloud_group, (f32x4*)dY, (f32x4*)ga_out,
                                                         (const f32x4*)ga_prev, (const f32x4*)gw_extra, gw_w ? (f32x4*)ws : nullptr);
     }
-    if (gw_w) k_cloud_group_sum<<<dim3(G), 256, 0, st>>>((const f32x4*)ws, group_cloud_off, (f32x4*)gw_w, (f32x4*)gw_b);
+    if (gw_w) k_cloud_group_sum<<<dim3(G), 1024, 0, st>>>((const f32x4*)ws, group_cloud_off, (f32x4*)gw_w, (f32x4*)gw_b);
     DD3D_CHECK_LAUNCH();
     return 0;
 }
