@@ -154,6 +154,12 @@ def main():
                 "peak": 157.3, "unit": "TFLOP/s", "traffic": None, "launches": len(ms), "avg_launch_us": avg_ms * 1e3,
                 "avg_pairs_per_launch": sum(pairs) / max(len(pairs), 1)}
         roof["frac"] = roof["achieved"] / roof["peak"]
+        # HBM bytes per launch of this kernel: PMC counters cannot be read from inside the process, so the figure comes from the
+        # committed rocprofv3 --pmc passes of this same command (tools/pmc.sh -> tools/pmc_to_json.py), corrected as the file says
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv128.json")
+        if args.path != "dropin" and args.ipc == IPC and os.path.exists(pmc):
+            roof["traffic"] = json.load(open(pmc))["traffic_bytes_per_launch_avg_real_syn"]
+            roof["traffic_source"] = "profiles/r01_pmc_conv128.json"
         out = {"metric": METRIC, "value": args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
                "data": "synthetic", "config": {"workload": f"cfg2: MNIST-3D-shaped stroke digits, {NUM_CLASSES} classes x {REAL_PER_CLASS} real clouds, "

@@ -9,15 +9,16 @@
 //   bwd-weight: dW[g][k] = sum_{o in group g} X[nbr[k][o]]^T . dY[o]   -> row-chunk partial slabs + fixed-order reduce (deterministic)
 // Cin == 3 (first layer) is a bandwidth kernel on the VALU (a 3-wide contraction has nothing for MFMA to do).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
 // Row-chunk sizes of the backward-weight kernels.  They are functions of the TRUE number of rows (group_row_off[G], read on the
 // device), never of the launch bound, so a launch over a bound (HIP-graph replay) sums in exactly the order of an exact launch.
-//   Cin = 3  : cheap chunks, aim for ~1024 of them, at least 64 rows each
+//   Cin = 3  : cheap chunks, aim for ~512 of them (two per CU), at least 64 rows each
 //   Cin = 128: about 256 row chunks per launch, at least 512 rows each; both multiples of 32
 __host__ __device__ __forceinline__ int chunk3(int M) {
-    int ch = (((M > 0 ? M : 1) + 1023) / 1024 + 31) / 32 * 32;
+    int ch = (((M > 0 ? M : 1) + 511) / 512 + 31) / 32 * 32;
     return ch < 64 ? 64 : ch;
 }
 __host__ __device__ __forceinline__ int chunk128(int M) {
@@ -25,7 +26,7 @@ __host__ __device__ __forceinline__ int chunk128(int M) {
     return ch < 512 ? 512 : ch;
 }
 // slots needed for ANY row count <= bound: the chunk size is smallest (64 / 512) when there are few rows
-inline int64_t max_slots3(int64_t bound, int G) { return ceil_div64(bound, 64) < 1024 + G ? ceil_div64(bound, 64) + G : 1024 + G; }
+inline int64_t max_slots3(int64_t bound, int G) { return ceil_div64(bound, 64) < 512 + G ? ceil_div64(bound, 64) + G : 512 + G; }
 inline int64_t max_slots128(int64_t bound, int G) { return ceil_div64(bound, 512) < 256 + G ? ceil_div64(bound, 512) + G : 256 + G; }
 
 // ---------------------------------------------------------------------------------------------
@@ -33,7 +34,7 @@ inline int64_t max_slots128(int64_t bound, int G) { return ceil_div64(bound, 512
 // ---------------------------------------------------------------------------------------------
 template <int TM, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256) void k_conv128(const float* __restrict__ X, const float* __restrict__ W, const int* __restrict__ nbr, int64_t ld,
-                                                 int K, int M_bound, const int* __restrict__ m_dev, int mirror, float* __restrict__ Y) {
+                                                 int K, int M_bound, const int* __restrict__ m_dev, int mirror, float* __restrict__ Y, int xcd_remap) {
     constexpr int BK = 32, LDA4 = 9 /* (BK+4)/4 float4 per A row: +16 B pad keeps ds_read_b128 conflict-free */;
     constexpr int WM = TM / WAVES_M, WN = 128 / WAVES_N, MT = WM / 32, NT = WN / 32;
     static_assert(WAVES_M * WAVES_N == 4 && MT >= 1 && NT >= 1, "4 waves");
@@ -45,9 +46,13 @@ __global__ __launch_bounds__(256) void k_conv128(const float* __restrict__ X, co
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int i32 = lane & 31, h = lane >> 5;
     const int wrow0 = (wid / WAVES_N) * WM, wcol0 = (wid % WAVES_N) * WN;
-    const int64_t row0 = (int64_t)blockIdx.x * TM;
     const int M_out = m_dev ? min(*m_dev, M_bound) : M_bound;  // launched over the bound, the true row count lives on the device
-    if (row0 >= M_out) return;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so XCD x takes the x-th
+    // contiguous eighth of the tiles: neighbouring tiles (whose gathers overlap) then share one L2 instead of eight.
+    const int ntile = (M_out + TM - 1) / TM, per_xcd = (ntile + 7) / 8;
+    const int tile = xcd_remap ? (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int64_t row0 = (int64_t)tile * TM;
+    if (tile >= ntile || (xcd_remap && (int)(blockIdx.x >> 3) >= per_xcd)) return;
 
     if (tid == 0) s_kmask = 0;
     __syncthreads();
@@ -264,72 +269,73 @@ __global__ __launch_bounds__(256) void k_conv128_bww(const float* __restrict__ X
     if (tid == 0) slab_valid[(int64_t)c * K + k] = 1;
 }
 
-// dW[g][k][e] = sum over the valid slabs of group g, in slot order (deterministic)
-__global__ void k_slab_reduce(const f32x4* __restrict__ slabs, const int* __restrict__ slab_valid, const int* __restrict__ group_row_off, int G, int cin3,
-                              int K, int elems4, f32x4* __restrict__ dW) {
-    int e = blockIdx.x * 256 + threadIdx.x;
-    int k = blockIdx.y, g = blockIdx.z;
-    if (e >= elems4) return;
+// dW[g][k][e] = sum over the valid slabs of group g.  4 slot-lanes walk the slots c = first+lane, first+lane+4, ... (4 independent chains), then the lanes are combined in lane order: deterministic.
+__global__ __launch_bounds__(256) void k_slab_reduce(const f32x4* __restrict__ slabs, const int* __restrict__ slab_valid,
+                                                     const int* __restrict__ group_row_off, int G, int cin3, int K, int elems4, f32x4* __restrict__ dW) {
+    __shared__ f32x4 s_red[256];
+    const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el;
+    const int k = blockIdx.y, g = blockIdx.z;
     const int CH = cin3 ? chunk3(group_row_off[G]) : chunk128(group_row_off[G]);
     int first = 0;
     for (int j = 0; j < g; ++j) first += (group_row_off[j + 1] - group_row_off[j] + CH - 1) / CH;
-    int n = (group_row_off[g + 1] - group_row_off[g] + CH - 1) / CH;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int c = first; c < first + n; ++c)
-        if (slab_valid[(int64_t)c * K + k]) s += slabs[((int64_t)c * K + k) * elems4 + e];
-    dW[((int64_t)g * K + k) * elems4 + e] = s;
+    const int n = (group_row_off[g + 1] - group_row_off[g] + CH - 1) / CH;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 s = zero;
+    const int ec = min(e, elems4 - 1);
+    if (cin3) {  // every slot of a group holds a slab: unconditional loads, several in flight
+#pragma unroll 4
+        for (int c = first + sl; c < first + n; c += 4) s += slabs[((int64_t)c * K + k) * elems4 + ec];
+    } else {     // most (chunk, offset) slabs of flat clouds do not exist: never touch those
+        for (int c = first + sl; c < first + n; c += 4)
+            if (slab_valid[(int64_t)c * K + k]) s += slabs[((int64_t)c * K + k) * elems4 + ec];
+    }
+    s_red[threadIdx.x] = s;
+    __syncthreads();
+    if (sl == 0 && e < elems4) dW[((int64_t)g * K + k) * elems4 + e] = s_red[el] + s_red[el + 64] + s_red[el + 128] + s_red[el + 192];
 }
 
 // ---------------------------------------------------------------------------------------------
 // Cin = 3, Cout = 128 (first layer): bandwidth kernels on the VALU
 // ---------------------------------------------------------------------------------------------
-// Y[o][:] = sum_k X[nbr[k][o]][0:3] . W[k][0:3][:] as a [64 x 96] x [96 x 128] product per tile on the fp32 matrix cores: the
-// im2col tile A[o][3k+ci] is gathered into LDS with coalesced neighbour-table reads (64 consecutive rows per offset), W sits in
-// LDS for the whole block (TILES tiles), and MFMA steps whose two columns belong to offsets without any neighbour in the tile are
-// skipped (z = 0 clouds only ever have 9 of the 27 offsets).  Column order inside a 32-chunk follows the MFMA operand layout
-// (lane half h supplies column 16h + s at step s), identical for A and W.
-template <int TILES>
+// Y[o][:] = sum_k X[nbr[k][o]][0:3] . W[k][0:3][:] as a [64 x 96] x [96 x 128] product per tile on the fp32 matrix cores.  The
+// im2col tile A[o][3 pos(k) + ci] is gathered into LDS with coalesced neighbour-table reads (64 consecutive rows per offset); the
+// wave's slice of W sits in registers.  Columns are ordered so that the nine offsets with no displacement along the first spatial
+// axis come first (pos < 9): clouds that are flat along that axis (MNIST: depth 0) then fill only the first of the three
+// 32-column chunks, and chunks without any neighbour in the tile are skipped as a whole.
+__device__ __forceinline__ int conv3_pos(int k) { return (k % 3 == 1 ? 0 : k % 3 == 0 ? 9 : 18) + k / 3; }   // offset -> column group
+__device__ __forceinline__ int conv3_off(int p) { return (p % 9) * 3 + (p < 9 ? 1 : p < 18 ? 0 : 2); }       // column group -> offset
+
 __global__ __launch_bounds__(256) void k_conv3_fwd(const float* __restrict__ X, const float* __restrict__ W /*[K][3][128]*/, const int* __restrict__ nbr,
                                                    int64_t ld, int K, int M_bound, const int* __restrict__ m_dev, float* __restrict__ Y) {
     constexpr int LDA = 97;
-    __shared__ float Ws[96 * 128];
     __shared__ float As[64 * LDA];
-    __shared__ unsigned s_kmask;
+    __shared__ unsigned s_pmask;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int i32 = lane & 31, h = lane >> 5;
     const int M_out = m_dev ? min(*m_dev, M_bound) : M_bound;
-    const int64_t first = (int64_t)blockIdx.x * TILES * 64;
-    if (first >= M_out) return;
-    {   // W -> LDS: all loads are issued before the first LDS write (a load-wait-store loop would serialise 12 L2 round trips)
-        const f32x4* W4 = (const f32x4*)W;
-        f32x4* Ws4 = (f32x4*)Ws;
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        f32x4 wreg[12];
+    if ((int64_t)blockIdx.x * 64 >= M_out) return;
+    // The wave's slice of W (96 columns x its 32 output channels) lives in REGISTERS for the whole kernel: lane (i32, h) holds exactly
+    // the B operands it feeds to the 48 MFMA steps.  48 coalesced loads per lane, issued together, once per workgroup.
+    float wv[48];
 #pragma unroll
-        for (int j = 0; j < 12; ++j) {
-            const int idx = j * 256 + tid;
-            wreg[j] = W4[min(idx, K * 3 * 32 - 1)];
-            if (idx >= K * 3 * 32) wreg[j] = zero;
-        }
-#pragma unroll
-        for (int j = 0; j < 12; ++j) Ws4[j * 256 + tid] = wreg[j];
+    for (int t = 0; t < 48; ++t) {
+        const int j = (t >> 4) * 32 + h * 16 + (t & 15);          // column of step t for this lane half
+        const int wrow = conv3_off(min(j, 80) / 3) * 3 + min(j, 80) % 3;
+        wv[t] = W[wrow * 128 + wid * 32 + i32];
+        if (j >= 81) wv[t] = 0.f;
     }
     for (int i = tid; i < 64 * LDA; i += 256) As[i] = 0.f;  // columns 81..96 stay zero
     const int sr = tid & 63, sk = tid >> 6;                 // staging: row of the tile, offset lane (4 lanes walk the 27 offsets)
-    for (int t = 0; t < TILES; ++t) {
-        const int64_t row0 = first + (int64_t)t * 64;
-        if (row0 >= M_out) break;
-        if (tid == 0) s_kmask = 0;
-        __syncthreads();  // previous tile's MFMA reads of As are done; W / zero fill visible
+    for (int64_t row0 = (int64_t)blockIdx.x * 64; row0 < M_out; row0 += (int64_t)gridDim.x * 64) {  // persistent: tiles strided by the grid
+        if (tid == 0) s_pmask = 0;
+        __syncthreads();  // previous tile's MFMA reads of As are done; zero fill visible
         unsigned mymask = 0;
         const int64_t row = min(row0 + sr, (int64_t)M_out - 1);  // clamped: every load below has a valid address, no branches,
         const bool live = row0 + sr < M_out;                     // so the 7 table loads and then the 7 gathers are all in flight
         int nb[7];
 #pragma unroll
-        for (int kk = 0; kk < 7; ++kk) {
-            const int k = min(sk + kk * 4, K - 1);
-            nb[kk] = nbr[(int64_t)k * ld + row];
-        }
+        for (int kk = 0; kk < 7; ++kk) nb[kk] = nbr[(int64_t)min(sk + kk * 4, 26) * ld + row];
         float xv[7][3];
 #pragma unroll
         for (int kk = 0; kk < 7; ++kk) {
@@ -339,36 +345,38 @@ __global__ __launch_bounds__(256) void k_conv3_fwd(const float* __restrict__ X, 
 #pragma unroll
         for (int kk = 0; kk < 7; ++kk) {
             const int k = sk + kk * 4;
-            if (k < K) {
+            if (k < 27) {
                 const bool ok = live && nb[kk] >= 0;
-                if (ok) mymask |= 1u << k;
-                As[sr * LDA + k * 3 + 0] = ok ? xv[kk][0] : 0.f;
-                As[sr * LDA + k * 3 + 1] = ok ? xv[kk][1] : 0.f;
-                As[sr * LDA + k * 3 + 2] = ok ? xv[kk][2] : 0.f;
+                const int p = conv3_pos(k);
+                if (ok) mymask |= 1u << p;
+                As[sr * LDA + p * 3 + 0] = ok ? xv[kk][0] : 0.f;
+                As[sr * LDA + p * 3 + 1] = ok ? xv[kk][1] : 0.f;
+                As[sr * LDA + p * 3 + 2] = ok ? xv[kk][2] : 0.f;
             }
         }
-        if (mymask) atomicOr(&s_kmask, mymask);
+        if (mymask) atomicOr(&s_pmask, mymask);
         __syncthreads();
-        const unsigned kmask = __builtin_amdgcn_readfirstlane(s_kmask);  // wave-uniform: the step skipping below is a scalar branch
+        const unsigned pmask = __builtin_amdgcn_readfirstlane(s_pmask);  // wave-uniform: chunk skipping is a scalar branch
         f32x16 acc[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
+        for (int q = 0; q < 3; ++q) {
+            // column groups touched by chunk q: columns [32q, 32q+32) = groups [32q/3, (32q+31)/3]
+            const unsigned groups = ((2u << ((q * 32 + 31) / 3)) - 1u) & ~((1u << (q * 32 / 3)) - 1u);
+            if (!(pmask & groups)) continue;
+            float av[2][16];
 #pragma unroll
-            for (int s2 = 0; s2 < 16; ++s2) {
-                const int j0 = q * 32 + s2, j1 = j0 + 16;  // the two columns of this MFMA step (lane halves h = 0, 1)
-                if (!(((kmask >> (j0 / 3)) | (kmask >> (j1 / 3))) & 1u)) continue;
-                const int j = h ? j1 : j0;
-                const float bv = Ws[j * 128 + wid * 32 + i32];
+            for (int s2 = 0; s2 < 16; ++s2)
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const float av = As[(m * 32 + i32) * LDA + j];
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m], 0, 0, 0);
-                }
-            }
+                for (int m = 0; m < 2; ++m) av[m][s2] = As[(m * 32 + i32) * LDA + q * 32 + h * 16 + s2];
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][s2], wv[q * 16 + s2], acc[m], 0, 0, 0);
+        }
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -422,12 +430,16 @@ __global__ __launch_bounds__(256) void k_conv3_bwd_data(const float* __restrict_
 }
 
 // dW[g][k][ci][co] partial per row chunk on the fp32 matrix cores: out[81 (pad 96)][128] = A^T . dY with the im2col tile
-// A[o][k*3+ci] = X[nbr[k][o]][ci] built in LDS (32 rows at a time).  Wave w owns output columns [32w, 32w+32) and all 3 row tiles.
+// A[o][3 pos(k) + ci] = X[nbr[k][o]][ci] built in LDS, 32 rows at a time (same column order as k_conv3_fwd, so flat clouds only
+// ever fill the first of the three 32-column output tiles and the other two are skipped).  Wave w owns output columns
+// [32w, 32w+32).  Two-stage software pipeline: while the matrix cores work on rows rb.., the gathers of rb+32.. and the
+// neighbour-table reads of rb+64.. are in flight; even and odd MFMA steps use separate accumulators (no dependent chain).
 __global__ __launch_bounds__(256) void k_conv3_bww(const float* __restrict__ X, const float* __restrict__ dY, const int* __restrict__ nbr, int64_t ld,
                                                    const int* __restrict__ group_row_off, int G, float* __restrict__ slabs, int* __restrict__ slab_valid) {
     constexpr int LDA = 97;  // 96 + 1: the im2col writes walk rows (stride LDA) and must not land on one bank
     __shared__ float As[32 * LDA];
     __shared__ f32x4 Ds4[32 * 32];
+    __shared__ unsigned s_pmask[2];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int i32 = lane & 31, h = lane >> 5;
     const int c = blockIdx.x;
@@ -435,56 +447,91 @@ __global__ __launch_bounds__(256) void k_conv3_bww(const float* __restrict__ X, 
     const int CH = chunk3(group_row_off[G]);
     if (!resolve_chunk(c, group_row_off, G, CH, &g, &r0, &r1)) return;
     for (int i = tid; i < 32 * LDA; i += 256) As[i] = 0.f;  // pad columns 81..96 stay zero
-    f32x16 acc[3];
+    if (tid < 2) s_pmask[tid] = 0;
+    f32x16 acc[4];  // output tile 0 (the one flat clouds use) has two accumulators: [0] even steps, [3] odd steps
 #pragma unroll
-    for (int m = 0; m < 3; ++m)
+    for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
     const f32x4* D4 = (const f32x4*)dY;
     const float* Ds = (const float*)Ds4;
     const int sr = tid & 31, sk = tid >> 5;  // staging: row within the sub-block, offset lane (8 lanes walk the 27 offsets)
-    __syncthreads();
-    for (int rb = r0; rb < r1; rb += 32) {
-        int row = rb + sr;
-        const int rowc = min(row, r1 - 1);  // clamped: branch-free loads, all four table reads then all four gathers in flight
-        int nb[4];
+    // every load is clamped to the chunk (valid address, no branch); rows beyond r1 are zeroed when they are written to LDS
+    auto load_nb = [&](int rb, int* nb) {
+        const int rowc = min(rb + sr, r1 - 1);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) nb[kk] = nbr[(int64_t)min(sk + kk * 8, 26) * ld + rowc];
-        float xv[4][3];
+    };
+    auto load_x = [&](const int* nb, float (*xv)[3]) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const float* x = X + (int64_t)max(nb[kk], 0) * 3;
             xv[kk][0] = x[0]; xv[kk][1] = x[1]; xv[kk][2] = x[2];
         }
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            int k = sk + kk * 8;
-            if (k < 27) {
-                const bool ok = row < r1 && nb[kk] >= 0;
-                As[sr * LDA + k * 3 + 0] = ok ? xv[kk][0] : 0.f;
-                As[sr * LDA + k * 3 + 1] = ok ? xv[kk][1] : 0.f;
-                As[sr * LDA + k * 3 + 2] = ok ? xv[kk][2] : 0.f;
-            }
-        }
+    };
+    auto load_d = [&](int rb, f32x4* d) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            int idx = j * 256 + tid;
-            int r = idx >> 5, q = idx & 31;
-            int rr = rb + r;
-            f32x4 d = {0.f, 0.f, 0.f, 0.f};
-            if (rr < r1) d = D4[(int64_t)rr * 32 + q];
-            Ds4[idx] = d;
+            const int idx = j * 256 + tid;
+            d[j] = D4[(int64_t)min(rb + (idx >> 5), r1 - 1) * 32 + (idx & 31)];
         }
-        __syncthreads();
+    };
+    auto store = [&](int rb, const int* nb, const float (*xv)[3], const f32x4* d, int par) {
+        unsigned mymask = 0;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            float b = Ds[(h * 16 + s) * 128 + wid * 32 + i32];
-#pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                float a = As[(h * 16 + s) * LDA + m * 32 + i32];
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[m], 0, 0, 0);
+        for (int kk = 0; kk < 4; ++kk) {
+            const int k = sk + kk * 8;
+            if (k < 27) {
+                const bool ok = rb + sr < r1 && nb[kk] >= 0;
+                const int p = conv3_pos(k);
+                if (ok) mymask |= 1u << p;
+                As[sr * LDA + p * 3 + 0] = ok ? xv[kk][0] : 0.f;
+                As[sr * LDA + p * 3 + 1] = ok ? xv[kk][1] : 0.f;
+                As[sr * LDA + p * 3 + 2] = ok ? xv[kk][2] : 0.f;
             }
         }
+        if (mymask) atomicOr(&s_pmask[par], mymask);
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = j * 256 + tid;
+            Ds4[idx] = rb + (idx >> 5) < r1 ? d[j] : zero;
+        }
+    };
+    int nbA[4], nbB[4];
+    float xv[4][3];
+    f32x4 d[4];
+    load_nb(r0, nbA);
+    load_nb(r0 + 32, nbB);
+    load_x(nbA, xv);
+    load_d(r0, d);
+    __syncthreads();  // zero fill and mask reset visible
+    store(r0, nbA, xv, d, 0);
+    __syncthreads();
+    int par = 0;
+    for (int rb = r0; rb < r1; rb += 32, par ^= 1) {
+        // stage 1 of rb+32 (gathers through the table entries read one iteration ago) and stage 0 of rb+64
+        load_x(nbB, xv);
+        load_d(rb + 32, d);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) nbA[kk] = nbB[kk];
+        load_nb(rb + 64, nbB);
+        const unsigned pmask = __builtin_amdgcn_readfirstlane(s_pmask[par]);
+        if (tid == 0) s_pmask[par ^ 1] = 0;  // last read two barriers ago, next written after the barrier below
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const unsigned groups = ((2u << ((m * 32 + 31) / 3)) - 1u) & ~((1u << (m * 32 / 3)) - 1u);  // column groups of output tile m
+            if (!(pmask & groups)) continue;
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) {
+                const float bv = Ds[(h * 16 + s2) * 128 + wid * 32 + i32];
+                const float av = As[(h * 16 + s2) * LDA + m * 32 + i32];
+                const int ai = (m == 0 && (s2 & 1)) ? 3 : m;
+                acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[ai], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (rb + 32 < r1) store(rb + 32, nbA, xv, d, par ^ 1);
         __syncthreads();
     }
     float* slab = slabs + (int64_t)c * (81 * 128);
@@ -492,8 +539,8 @@ __global__ __launch_bounds__(256) void k_conv3_bww(const float* __restrict__ X, 
     for (int m = 0; m < 3; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (row < 81) slab[row * 128 + wid * 32 + i32] = acc[m][r];
+            const int col = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;  // permuted im2col column -> row (k*3 + ci) of the kernel gradient
+            if (col < 81) slab[(conv3_off(col / 3) * 3 + col % 3) * 128 + wid * 32 + i32] = m == 0 ? acc[0][r] + acc[3][r] : acc[m][r];
         }
     if (tid == 0) slab_valid[c] = 1;
 }
@@ -535,11 +582,19 @@ DD3D_API int dd3d_conv_fwd(const float* X, int64_t M_in, int Cin, const float* W
     hipStream_t st = (hipStream_t)stream;
     if (Cin == 3) {
         if (mirror) return DD3D_EARG;
-        k_conv3_fwd<2><<<dim3((unsigned)ceil_div64(M_out, 128)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, Y);
-    } else if (M_out >= 128 * 512) {
-        k_conv128<128, 2, 2><<<dim3((unsigned)ceil_div64(M_out, 128)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y);
+        const int64_t tiles = ceil_div64(M_out, 64);
+        k_conv3_fwd<<<dim3((unsigned)(tiles < 512 ? tiles : 512)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, Y);
     } else {
-        k_conv128<64, 1, 4><<<dim3((unsigned)ceil_div64(M_out, 64)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y);
+        static const int dbg_tile = getenv("DD3D_CONV_TILE") ? atoi(getenv("DD3D_CONV_TILE")) : 0;
+        static const int dbg_xcd = getenv("DD3D_CONV_XCD") ? atoi(getenv("DD3D_CONV_XCD")) : 0;
+        const bool big = dbg_tile ? dbg_tile == 128 : M_out >= 128 * 512;
+        if (big) {
+            const int64_t nt = ceil_div64(M_out, 128);
+            k_conv128<128, 2, 2><<<dim3((unsigned)(ceil_div64(nt, 8) * 8)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, dbg_xcd);
+        } else {
+            const int64_t nt = ceil_div64(M_out, 64);
+            k_conv128<64, 1, 4><<<dim3((unsigned)(ceil_div64(nt, 8) * 8)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, dbg_xcd);
+        }
     }
     DD3D_CHECK_LAUNCH();
     return 0;
@@ -580,10 +635,10 @@ DD3D_API int dd3d_conv_bwd_weight(const float* X, int Cin, const float* dY, int 
             k_conv128_bww<<<dim3((unsigned)slots, K), 256, 0, st>>>(X, dY, nbr, ld, K, group_row_off, G, slabs, valid);
     }
     if (Cin == 3)
-        k_slab_reduce<<<dim3((unsigned)ceil_div64(per / 4, 256), 1, G), 256, 0, st>>>((const f32x4*)slabs, valid, group_row_off, G, 1, 1, (int)(per / 4),
+        k_slab_reduce<<<dim3((unsigned)ceil_div64(per / 4, 64), 1, G), 256, 0, st>>>((const f32x4*)slabs, valid, group_row_off, G, 1, 1, (int)(per / 4),
                                                                                      (f32x4*)dW);
     else
-        k_slab_reduce<<<dim3((unsigned)ceil_div64(per / 4, 256), K, G), 256, 0, st>>>((const f32x4*)slabs, valid, group_row_off, G, 0, K, (int)(per / 4),
+        k_slab_reduce<<<dim3((unsigned)ceil_div64(per / 4, 64), K, G), 256, 0, st>>>((const f32x4*)slabs, valid, group_row_off, G, 0, K, (int)(per / 4),
                                                                                      (f32x4*)dW);
     DD3D_CHECK_LAUNCH();
     return 0;
