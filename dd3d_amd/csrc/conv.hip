@@ -16,7 +16,8 @@ namespace {
 // Row-chunk sizes of the backward-weight kernels.  They are functions of the TRUE number of rows (group_row_off[G], read on the
 // device), never of the launch bound, so a launch over a bound (HIP-graph replay) sums in exactly the order of an exact launch.
 //   Cin = 3  : cheap chunks, aim for ~512 of them (two per CU), at least 64 rows each
-//   Cin = 128: about 256 row chunks per launch, at least 512 rows each; both multiples of 32
+//   Cin = 128: about 256 row chunks per launch, at least 512 rows each (measured: fewer, larger chunks are slower even when they
+//              fit the resident slots exactly -- the per-chunk compaction phases overlap better across many workgroups)
 __host__ __device__ __forceinline__ int chunk3(int M) {
     int ch = (((M > 0 ? M : 1) + 511) / 512 + 31) / 32 * 32;
     return ch < 64 ? 64 : ch;
@@ -225,21 +226,35 @@ __global__ __launch_bounds__(256) void k_conv128_bww(const float* __restrict__ X
             __syncthreads();
         }
         if (total) have_any = true;
-        for (int sb = 0; sb < total; sb += 32) {
+        // 32 compacted pairs per MFMA block; the rows of block sb+32 are fetched into registers while the matrix cores work on sb
+        f32x4 ra[4], rd[4];
+        auto fetch = [&](int sb) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                int idx = j * 256 + tid;
-                int r = idx >> 5, q = idx & 31;
-                int e = sb + r;
-                f32x4 a = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
-                if (e < total) {
-                    a = X4[(int64_t)s_nb[e] * 32 + q];
-                    d = D4[(int64_t)s_row[e] * 32 + q];
-                }
-                As4[idx] = a;
-                Ds4[idx] = d;
+                const int idx = j * 256 + tid;
+                const int e = min(sb + (idx >> 5), total - 1);  // clamped: branch-free, all 8 loads in flight
+                ra[j] = X4[(int64_t)s_nb[e] * 32 + (idx & 31)];
+                rd[j] = D4[(int64_t)s_row[e] * 32 + (idx & 31)];
             }
-            __syncthreads();
+        };
+        auto stage = [&](int sb) {
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int idx = j * 256 + tid;
+                const bool ok = sb + (idx >> 5) < total;
+                As4[idx] = ok ? ra[j] : zero;
+                Ds4[idx] = ok ? rd[j] : zero;
+            }
+        };
+        if (total) {
+            fetch(0);
+            stage(0);
+        }
+        __syncthreads();
+        for (int sb = 0; sb < total; sb += 32) {
+            const bool more = sb + 32 < total;
+            if (more) fetch(sb + 32);
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 float a[2], b[2];
@@ -253,9 +268,14 @@ __global__ __launch_bounds__(256) void k_conv128_bww(const float* __restrict__ X
                     for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
             }
             __syncthreads();
+            if (more) stage(sb + 32);
+            __syncthreads();
         }
     }
-    if (!have_any) return;
+    if (!have_any) {
+        if (tid == 0) slab_valid[(int64_t)c * K + k] = 0;  // every resolved (chunk, offset) writes its flag: no memset of the flags
+        return;
+    }
     float* slab = slabs + ((int64_t)c * K + k) * (128 * 128);
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -626,7 +646,6 @@ DD3D_API int dd3d_conv_bwd_weight(const float* X, int Cin, const float* dY, int 
     int64_t per = (Cin == 3) ? (int64_t)K * 3 * Cout : (int64_t)Cin * Cout;
     float* slabs = (float*)ws;
     int* valid = (int*)((char*)ws + align_up64(nslab * per * 4, 256));
-    DD3D_HIP(hipMemsetAsync(valid, 0, nslab * 4, st));
     if (M_out > 0) {
         if (!X || !dY || !nbr) return DD3D_EARG;
         if (Cin == 3)
