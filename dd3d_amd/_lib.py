@@ -43,7 +43,7 @@ _SIGS = {
     "dd3d_gather_clouds": (I32, [P, P, I32, P, I32, I32, I64, P, P, P, P, P, P]),
     "dd3d_cloud_maps_max_points": (I32, []),
     "dd3d_cloud_maps_ws_bytes": (I64, [I32]),
-    "dd3d_cloud_maps": (I32, [P, P, I32, I32, I64, P, I32, I32, I32, I32] + [P] * 17 + [I64, P, P, P, P, P, I64, P]),
+    "dd3d_cloud_maps": (I32, [P, P, I32, I32, I64, P, I32, I32, I32, I32] + [P] * 17 + [I64, P, P, P, P, P, P, P, I64, P]),
     "dd3d_conv_fwd": (I32, [P, I64, I32, P, I32, P, I64, I32, I64, P, I32, P, P]),
     "dd3d_conv_bwd_data": (I32, [P, I64, P, I32, P, I32, P, I64, I32, P, P]),
     "dd3d_conv_bwd_weight_ws_bytes": (I64, [I64, I32, I32, I32, I32]),
@@ -64,7 +64,7 @@ _SIGS = {
     "dd3d_sparse_linear_bwd_w": (I32, [P, P, P, I32, I32, P, I32, I32, I32, P, P, I64, P]),
     "dd3d_classifier_layout": (I32, [P, I32, I32, I32, I32, I32, P, P]),
     "dd3d_softmax_ce": (I32, [P, P, P, P, I32, I32, I32, P, P, P, P, P]),
-    "dd3d_softmax_ce_bwd2": (I32, [P, P, P, I32, I32, I32, P, P]),
+    "dd3d_softmax_ce_bwd2": (I32, [P, P, P, P, I32, I32, I32, P, P]),
     "dd3d_match_loss_ws_bytes": (I64, [P, I32, I32]),
     "dd3d_match_loss_stats_floats": (I64, [P, I32, I32]),
     "dd3d_match_loss_fwd": (I32, [P, I32, I32, I32, P, P, P, I64, P]),

@@ -188,7 +188,8 @@ __global__ __launch_bounds__(CT) void k_cloud_count(const float4* __restrict__ c
 }
 
 // ---- scan: seg[l][0..B] = exclusive prefix of cnt[l][0..B), counts[l] = total, for the three levels (one block) ----
-__global__ void k_cloud_scan(const int* __restrict__ cnt, int B, int* __restrict__ seg /*[3][B+1]*/, int* __restrict__ counts /*[3]*/) {
+__global__ void k_cloud_scan(const int* __restrict__ cnt, int B, int* __restrict__ seg /*[3][B+1]*/, int* __restrict__ counts /*[3]*/,
+                             const int* __restrict__ group_cloud_off, int G, int* __restrict__ gro /*[3][G+1] or null*/) {
     __shared__ int s_w[16];
     __shared__ int s_carry;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -224,6 +225,9 @@ __global__ void k_cloud_scan(const int* __restrict__ cnt, int B, int* __restrict
             counts[l] = s_carry;
         }
         __syncthreads();
+        // first row of every group of clouds at this stride (what the per-group reductions of the feature kernels walk)
+        if (gro)
+            for (int g = threadIdx.x; g <= G; g += 1024) gro[l * (G + 1) + g] = seg[l * (B + 1) + group_cloud_off[g]];
     }
 }
 
@@ -371,14 +375,14 @@ __global__ __launch_bounds__(CT) void k_cloud_emit(const float4* __restrict__ co
 
 template <int NMAX>
 int launch_cloud_maps(const float4* coords, const int* pt_off, int B, const int* cloud_group, int* cnt, int* seg, int* counts, const CloudOut& o,
-                      int* gmin, int* err, hipStream_t st) {
+                      int* gmin, int* err, const int* group_cloud_off, int G, int* gro, hipStream_t st) {
     const size_t smem = sizeof(CloudSmem<NMAX>);
     if (smem > 64 * 1024) {
         DD3D_HIP(hipFuncSetAttribute((const void*)k_cloud_count<NMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         DD3D_HIP(hipFuncSetAttribute((const void*)k_cloud_emit<NMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     }
     k_cloud_count<NMAX><<<dim3(B), CT, smem, st>>>(coords, pt_off, B, cloud_group, cnt, gmin, err);
-    k_cloud_scan<<<1, 1024, 0, st>>>(cnt, B, seg, counts);
+    k_cloud_scan<<<1, 1024, 0, st>>>(cnt, B, seg, counts, group_cloud_off, G, gro);
     k_cloud_emit<NMAX><<<dim3(B), CT, smem, st>>>(coords, pt_off, B, cloud_group, seg, o, err);
     DD3D_CHECK_LAUNCH();
     return 0;
@@ -395,7 +399,8 @@ DD3D_API int dd3d_cloud_maps(const float* coords, const int32_t* pt_off, int B, 
                              int E0, int E1, int E2, int32_t* counts /*[3]*/, int32_t* seg /*[3][B+1]*/, int32_t* C1, int32_t* C2, int32_t* C4,
                              int32_t* inv1, int32_t* uidx1, int32_t* vox_off, int32_t* vox_pts, int32_t* par2, int32_t* uidx2, int32_t* par4,
                              int32_t* uidx4, int32_t* nbr1, int32_t* nbr2, int32_t* kid2, int32_t* kid4, int64_t ld, int32_t* gmin, int32_t* site,
-                             int32_t* vox_at, int32_t* err_dev, void* ws, int64_t ws_bytes, void* stream) {
+                             int32_t* vox_at, const int32_t* group_cloud_off, int32_t* group_row_off /*[3][G+1]*/, int32_t* err_dev, void* ws,
+                             int64_t ws_bytes, void* stream) {
     if (B < 0 || max_points <= 0 || max_points > dd3d_cloud_maps_max_points() || bound < 0 || ld < bound || G <= 0 || !counts || !seg || !err_dev)
         return DD3D_EARG;
     if (bound >= (1ll << 31) / 32) return DD3D_ESIZE;
@@ -403,6 +408,7 @@ DD3D_API int dd3d_cloud_maps(const float* coords, const int32_t* pt_off, int B, 
     const bool dense = site != nullptr;
     if (dense && (!gmin || E0 <= 0 || E1 <= 0 || E2 <= 0)) return DD3D_EARG;
     if (vox_at && !dense) return DD3D_EARG;
+    if (group_row_off && !group_cloud_off) return DD3D_EARG;
     hipStream_t st = (hipStream_t)stream;
     if (dense) {
         DD3D_HIP(hipMemsetAsync(gmin, 0x7F, (size_t)G * 3 * 4, st));
@@ -411,6 +417,7 @@ DD3D_API int dd3d_cloud_maps(const float* coords, const int32_t* pt_off, int B, 
     if (B == 0) {
         DD3D_HIP(hipMemsetAsync(counts, 0, 12, st));
         DD3D_HIP(hipMemsetAsync(seg, 0, 12, st));
+        if (group_row_off) DD3D_HIP(hipMemsetAsync(group_row_off, 0, (size_t)3 * (G + 1) * 4, st));
         if (vox_off) DD3D_HIP(hipMemsetAsync(vox_off, 0, 4, st));
         return 0;
     }
@@ -426,6 +433,6 @@ DD3D_API int dd3d_cloud_maps(const float* coords, const int32_t* pt_off, int B, 
     o.ld = ld; o.E0 = E0; o.E1 = E1; o.E2 = E2;
     int* cnt = (int*)ws;
     if (max_points <= 256)
-        return launch_cloud_maps<256>((const float4*)coords, pt_off, B, cloud_group, cnt, seg, counts, o, dense ? gmin : nullptr, err_dev, st);
-    return launch_cloud_maps<1024>((const float4*)coords, pt_off, B, cloud_group, cnt, seg, counts, o, dense ? gmin : nullptr, err_dev, st);
+        return launch_cloud_maps<256>((const float4*)coords, pt_off, B, cloud_group, cnt, seg, counts, o, dense ? gmin : nullptr, err_dev, group_cloud_off, G, group_row_off, st);
+    return launch_cloud_maps<1024>((const float4*)coords, pt_off, B, cloud_group, cnt, seg, counts, o, dense ? gmin : nullptr, err_dev, group_cloud_off, G, group_row_off, st);
 }

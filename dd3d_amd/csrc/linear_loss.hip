@@ -207,8 +207,8 @@ __global__ void k_group_sum_rows(const float* __restrict__ v, const int* __restr
 }
 
 // second order: dlogits = (softmax(z) - onehot)/B_g ; given u = dL/d(dlogits) -> dz = p * (u - <p,u>) / B_g
-__global__ void k_softmax_ce_bwd2(const float* __restrict__ prob, const float* __restrict__ u, const int* __restrict__ group_cloud_off, int G, int J,
-                                  float* __restrict__ dz) {
+__global__ void k_softmax_ce_bwd2(const float* __restrict__ prob, const float* __restrict__ u, const float* __restrict__ u_group /*[G][J] or null*/,
+                                  const int* __restrict__ group_cloud_off, int G, int J, float* __restrict__ dz) {
     int g = blockIdx.y;
     int b = group_cloud_off[g] + blockIdx.x * blockDim.x + threadIdx.x;
     int b1 = group_cloud_off[g + 1];
@@ -216,9 +216,10 @@ __global__ void k_softmax_ce_bwd2(const float* __restrict__ prob, const float* _
     float inv = 1.0f / (float)(b1 - group_cloud_off[g]);
     const float* p = prob + (int64_t)b * J;
     const float* uu = u + (int64_t)b * J;
+    const float* ug = u_group ? u_group + (int64_t)g * J : nullptr;   // per-group term of u (the gradient through gw[bias] = sum dlogits)
     float d = 0.f;
-    for (int j = 0; j < J; ++j) d += p[j] * uu[j];
-    for (int j = 0; j < J; ++j) dz[(int64_t)b * J + j] = p[j] * (uu[j] - d) * inv;
+    for (int j = 0; j < J; ++j) d += p[j] * (uu[j] + (ug ? ug[j] : 0.f));
+    for (int j = 0; j < J; ++j) dz[(int64_t)b * J + j] = p[j] * (uu[j] + (ug ? ug[j] : 0.f) - d) * inv;
 }
 
 // ---- gradient distance ------------------------------------------------------------------------------------------
@@ -512,10 +513,10 @@ DD3D_API int dd3d_group_sum_rows(const float* v, const int32_t* group_cloud_off,
     return 0;
 }
 
-DD3D_API int dd3d_softmax_ce_bwd2(const float* prob, const float* u, const int32_t* group_cloud_off, int G, int J, int max_clouds_per_group, float* dz,
-                                  void* stream) {
+DD3D_API int dd3d_softmax_ce_bwd2(const float* prob, const float* u, const float* u_group, const int32_t* group_cloud_off, int G, int J,
+                                  int max_clouds_per_group, float* dz, void* stream) {
     if (G <= 0 || J <= 0 || max_clouds_per_group <= 0 || !prob || !u || !group_cloud_off || !dz) return DD3D_EARG;
-    k_softmax_ce_bwd2<<<dim3((max_clouds_per_group + 63) / 64, G), 64, 0, (hipStream_t)stream>>>(prob, u, group_cloud_off, G, J, dz);
+    k_softmax_ce_bwd2<<<dim3((max_clouds_per_group + 63) / 64, G), 64, 0, (hipStream_t)stream>>>(prob, u, u_group, group_cloud_off, G, J, dz);
     DD3D_CHECK_LAUNCH();
     return 0;
 }

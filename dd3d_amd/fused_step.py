@@ -49,7 +49,7 @@ class _Pass:
         self.static = static
         if pt_off is not None and 0 < max_points <= int(L.lib.dd3d_cloud_maps_max_points()):
             # clouds small enough for LDS: the whole pyramid (+ dense placement) in three launches
-            cm = CloudCoordinateManager(coords, pt_off, B, max_points, net.dense_extent, cloud_group, G)
+            cm = CloudCoordinateManager(coords, pt_off, B, max_points, net.dense_extent, cloud_group, G, group_cloud_off)
         else:
             cm = CoordinateManager(coords, B, n_dev=n_dev)
         self.cm = cm
@@ -58,8 +58,11 @@ class _Pass:
         k1, p1 = cm.kernel_map(2, 2, 3), cm.kernel_map(2, 4, 2)
         seg1, seg2 = cm.seg_off(1), cm.seg_off(2)
         self.dp = DensePlacement(cm, 4, net.dense_extent, cloud_group, G, group_cloud_off)
-        gidx = group_cloud_off.long()
-        gro1, gro2 = seg1[gidx].contiguous(), seg2[gidx].contiguous()   # rows of every group at tensor strides 1 and 2
+        if getattr(cm, "group_row_off", None) is not None:
+            gro1, gro2 = cm.group_row_off[0], cm.group_row_off[1]
+        else:
+            gidx = group_cloud_off.long()
+            gro1, gro2 = seg1[gidx].contiguous(), seg2[gidx].contiguous()   # rows of every group at tensor strides 1 and 2
         self._pre = (k0, p0, k1, p1, seg1, seg2, gro1, gro2)
 
     def run(self, feats, labels, keep_ga: bool):
@@ -170,10 +173,9 @@ class _Pass:
         u = _empty((B, J), dev)
         L.call("dd3d_sparse_linear_fwd", L.ptr(self.P1), L.ptr(dp.site), L.ptr(dp.seg_off), B, 128, L.ptr(self.cloud_group), L.ptr(Gsm), sst, J,
                None, L.ptr(u), st)
-        u += G_cb[self.cloud_group.long()]
         dz = _empty((B, J), dev)
         per = int((self.gco[1:] - self.gco[:-1]).max().item()) if self._max_per is None else self._max_per
-        L.call("dd3d_softmax_ce_bwd2", L.ptr(self.prob), L.ptr(u), L.ptr(self.gco), G, J, per, L.ptr(dz), st)
+        L.call("dd3d_softmax_ce_bwd2", L.ptr(self.prob), L.ptr(u), L.ptr(G_cb), L.ptr(self.gco), G, J, per, L.ptr(dz), st)
         # H = dL/dP1: through dense in gw[W] (weights G_cw, coefficients dlogits) and through the logits (weights W, coefficients dz)
         H = _empty((M2, 128), dev)
         L.call("dd3d_sparse_linear_bwd_x", L.ptr(self.dl), L.ptr(dp.site), L.ptr(dp.seg_off), B, 128, L.ptr(self.cloud_group), L.ptr(Gsm), sst, J,

@@ -203,7 +203,7 @@ class CloudCoordinateManager(CoordinateManager):
     bit-identical to what ``CoordinateManager`` builds call by call; other strides / kernel sizes are not available here."""
 
     def __init__(self, coords: torch.Tensor, pt_off: torch.Tensor, num_clouds: int, max_points: int, dense_extent=None,
-                 cloud_group: Optional[torch.Tensor] = None, num_groups: int = 1):
+                 cloud_group: Optional[torch.Tensor] = None, num_groups: int = 1, group_cloud_off: Optional[torch.Tensor] = None):
         if coords.dim() != 2 or coords.shape[1] != 4:
             raise ValueError("coordinates must be [N,4] = (batch, c1, c2, c3)")
         coords = coords.detach().to(torch.float32).contiguous()
@@ -214,8 +214,8 @@ class CloudCoordinateManager(CoordinateManager):
         dev = self.device = coords.device
         self.N = int(coords.shape[0])
         self.coords, self._B, self.n_dev = coords, int(num_clouds), pt_off[num_clouds:]
-        self.counts = torch.zeros(self.MAX_LEVELS, dtype=_I32, device=dev)
-        self.err = torch.zeros(1, dtype=_I32, device=dev)
+        flags = torch.zeros(self.MAX_LEVELS + 1, dtype=_I32, device=dev)   # one fill: row counts + the error word
+        self.counts, self.err = flags[:self.MAX_LEVELS], flags[self.MAX_LEVELS:]
         self.levels, self.kmaps, self._synced = {}, {}, False
         B, bound = self._B, max(self.N, 1)
         i32 = lambda *shape: torch.empty(shape, dtype=_I32, device=dev)
@@ -230,11 +230,13 @@ class CloudCoordinateManager(CoordinateManager):
             E = tuple(int(e) for e in dense_extent)
             gmin, site, vox_at = i32(num_groups, 3), i32(bound), i32(E[0] * E[1] * E[2], max(B, 1))
             self.dense_tables = (E, cloud_group, gmin, site, vox_at)
+        self.group_row_off = i32(3, num_groups + 1) if group_cloud_off is not None else None   # rows of every group at strides 1, 2, 4
         ws = L.workspace(int(L.lib.dd3d_cloud_maps_ws_bytes(B)), dev)
         L.call("dd3d_cloud_maps", L.ptr(coords), L.ptr(pt_off), B, int(max_points), self.N, L.ptr(cloud_group), int(num_groups), E[0], E[1], E[2],
                L.ptr(self.counts), L.ptr(seg), L.ptr(C[0]), L.ptr(C[1]), L.ptr(C[2]), L.ptr(inv1), L.ptr(uidx1), L.ptr(self.vox_off),
                L.ptr(self.vox_pts), L.ptr(par2), L.ptr(uidx2), L.ptr(par4), L.ptr(uidx4), L.ptr(nbr1), L.ptr(nbr2), L.ptr(kid2), L.ptr(kid4), bound,
-               L.ptr(gmin), L.ptr(site), L.ptr(vox_at), L.ptr(self.err), L.ptr(ws), ws.numel(), L.stream())
+               L.ptr(gmin), L.ptr(site), L.ptr(vox_at), L.ptr(group_cloud_off), L.ptr(self.group_row_off), L.ptr(self.err), L.ptr(ws), ws.numel(),
+               L.stream())
         for slot, (stride, inv, uidx) in enumerate(((1, inv1, uidx1), (2, par2, uidx2), (4, par4, uidx4))):
             lv = _Level()
             lv.stride, lv.bound, lv.slot, lv.cap, lv.table = stride, self.N, slot, 0, None
