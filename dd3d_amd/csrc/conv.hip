@@ -611,9 +611,13 @@ DD3D_API int dd3d_conv_fwd(const float* X, int64_t M_in, int Cin, const float* W
         if (big) {
             const int64_t nt = ceil_div64(M_out, 128);
             k_conv128<128, 2, 2><<<dim3((unsigned)(ceil_div64(nt, 8) * 8)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, dbg_xcd);
-        } else {
+        } else if (dbg_tile ? dbg_tile == 64 : M_out >= 32 * 1024) {
             const int64_t nt = ceil_div64(M_out, 64);
             k_conv128<64, 1, 4><<<dim3((unsigned)(ceil_div64(nt, 8) * 8)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, dbg_xcd);
+        } else {
+            // small launches (the synthetic batch): 32-row tiles so that every CU holds several workgroups whose load latencies overlap
+            const int64_t nt = ceil_div64(M_out, 32);
+            k_conv128<32, 1, 4><<<dim3((unsigned)(ceil_div64(nt, 8) * 8)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, dbg_xcd);
         }
     }
     DD3D_CHECK_LAUNCH();
