@@ -19,6 +19,7 @@ for name, coords, B in (("real", b["coordinates"], 2560), ("syn", sc, 100)):
     M = cm.num_rows(2)
     pairs = int((nbr[:, :M] >= 0).sum())
     X = torch.randn(M, 128, device=dev)
+    assert int(nbr[:, :M].max()) < X.shape[0] and ld >= M  # every gathered row exists
     W = torch.randn(27, 128, 128, device=dev) * 0.05
     Y = torch.empty(M, 128, device=dev)
     def run():
