@@ -65,14 +65,14 @@ __device__ __forceinline__ f32x4 block_colsum(f32x4 v, f32x4* s_red /*[8*32]*/) 
 // rows in registers, so a cloud of <= RL*CACHE rows is read from HBM exactly once (mean, variance and the normalised write all
 // work on the registers); longer clouds re-read their tail (L2).  Sums run over a thread's rows in ascending order, then over the
 // row-lanes in lane order: deterministic.
-template <int RL>
-__device__ __forceinline__ f32x4 cloud_colsum(f32x4 v, f32x4* s_red /*[RL*32]*/) {
-    const int c4 = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    s_red[rl * 32 + c4] = v;
+template <int RL, int CL = 32>
+__device__ __forceinline__ f32x4 cloud_colsum(f32x4 v, f32x4* s_red /*[RL*CL]*/) {
+    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+    s_red[rl * CL + cl] = v;
     __syncthreads();
-    f32x4 s = s_red[c4];
+    f32x4 s = s_red[cl];
 #pragma unroll 4
-    for (int j = 1; j < RL; ++j) s += s_red[j * 32 + c4];
+    for (int j = 1; j < RL; ++j) s += s_red[j * CL + cl];
     __syncthreads();
     return s;
 }
@@ -286,15 +286,17 @@ __global__ __launch_bounds__(256) void k_arp_reduce(const f32x4* __restrict__ pa
 // Backward of pool -> ReLU -> affine -> instance norm in ONE pass over a cloud (k_arp_bwd followed by k_inorm_bwd, without the
 // round trip of g_xhat through HBM): the thread's rows of g_xhat and xhat stay in registers between the statistics and the final
 // write.  Per-cloud partial sums of ga*xhat / ga go to part[b][2][32]; k_cloud_group_sum folds them per group in cloud order.
-template <int RL, int CACHE>
-__global__ __launch_bounds__(RL * 32) void k_arp_inorm_bwd(const f32x4* __restrict__ g_pool, const int4* __restrict__ arg, const int* __restrict__ parent,
+// grid (cloud, 32 / CL): a workgroup takes CL float4 channel-lanes (CL * 16 B of every row), so several workgroups per CU overlap
+// their gather latencies
+template <int RL, int CACHE, int CL>
+__global__ __launch_bounds__(RL * CL) void k_arp_inorm_bwd(const f32x4* __restrict__ g_pool, const int4* __restrict__ arg, const int* __restrict__ parent,
                                                            const f32x4* __restrict__ xhat, const f32x4* __restrict__ inv_std,
                                                            const f32x4* __restrict__ w, const f32x4* __restrict__ bias,
                                                            const int* __restrict__ seg_off, const int* __restrict__ cloud_group,
                                                            f32x4* __restrict__ dY, f32x4* __restrict__ ga_out, const f32x4* __restrict__ ga_prev,
                                                            const f32x4* __restrict__ gw_extra, f32x4* __restrict__ part /*[B][2][32] or null*/) {
-    __shared__ f32x4 s_red[RL * 32];
-    const int b = blockIdx.x, c4 = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    __shared__ f32x4 s_red[RL * CL];
+    const int b = blockIdx.x, c4 = blockIdx.y * CL + threadIdx.x % CL, rl = threadIdx.x / CL;
     const int r0 = seg_off[b], r1 = seg_off[b + 1];
     const int n = r1 - r0;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -347,11 +349,11 @@ __global__ __launch_bounds__(RL * 32) void k_arp_inorm_bwd(const f32x4* __restri
         s1 += gx;
         s2 += gx * xh;
     }
-    const f32x4 m1 = cloud_colsum<RL>(s1, s_red) / (float)n;
-    const f32x4 m2 = cloud_colsum<RL>(s2, s_red) / (float)n;
+    const f32x4 m1 = cloud_colsum<RL, CL>(s1, s_red) / (float)n;
+    const f32x4 m2 = cloud_colsum<RL, CL>(s2, s_red) / (float)n;
     if (part) {
-        const f32x4 tw = cloud_colsum<RL>(sw, s_red);
-        const f32x4 tb = cloud_colsum<RL>(sb, s_red);
+        const f32x4 tw = cloud_colsum<RL, CL>(sw, s_red);
+        const f32x4 tb = cloud_colsum<RL, CL>(sb, s_red);
         if (rl == 0) {
             part[((int64_t)b * 2 + 0) * 32 + c4] = tw;
             part[((int64_t)b * 2 + 1) * 32 + c4] = tb;
@@ -507,7 +509,7 @@ DD3D_API int dd3d_arp_inorm_bwd(const float* g_pool, const int32_t* arg, const i
     hipStream_t st = (hipStream_t)stream;
     if (B > 0) {
         if (!g_pool || !arg || !parent || !xhat || !inv_std || !seg_off || !dY) return DD3D_EARG;
-        k_arp_inorm_bwd<32, 4><<<dim3(B), 1024, 0, st>>>((const f32x4*)g_pool, (const int4*)arg, parent, (const f32x4*)xhat, (const f32x4*)inv_std,
+        k_arp_inorm_bwd<32, 4, 16><<<dim3(B, 2), 512, 0, st>>>((const f32x4*)g_pool, (const int4*)arg, parent, (const f32x4*)xhat, (const f32x4*)inv_std,
                                                         (const f32x4*)w, (const f32x4*)b, seg_off, cloud_group, (f32x4*)dY, (f32x4*)ga_out,
                                                         (const f32x4*)ga_prev, (const f32x4*)gw_extra, gw_w ? (f32x4*)ws : nullptr);
     }
