@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--ipc", type=int, default=IPC)
     ap.add_argument("--metric-name", default="modmse", help="dist_opt: modmse (INI default) | ours | mse | cos")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--emulate-shard", default="", help="R/W: time rank R's share of a W-rank job on this one GPU (no process group)")
     ap.add_argument("--path", default="graph", choices=["graph", "fused", "dropin"],
                     help="graph: class-batched step captured into one HIP graph (default); fused: the same step enqueued eagerly; "
                          "dropin: the reference-shaped autograd loop")
@@ -70,9 +71,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or os.environ.get("DD3D_FORCE_DIST"):   # DD3D_FORCE_DIST: rehearse the RCCL path with a single rank
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     from dd3d_amd.mnist_distill import Distiller
     from dd3d_amd.fused_step import FusedDistiller
@@ -86,6 +89,9 @@ def main():
     syn = init_synthetic(NUM_CLASSES, args.ipc, NUM_POINTS, seed=0)
     from dd3d_amd.sharding import max_over_ranks, owned_classes, reduce_loss
     my_classes = owned_classes(NUM_CLASSES, rank, world)
+    if args.emulate_shard:
+        er, ew = (int(x) for x in args.emulate_shard.split("/"))
+        my_classes = owned_classes(NUM_CLASSES, er, ew)
     kw = dict(ipc=args.ipc, num_classes=NUM_CLASSES, num_points=NUM_POINTS, batch_size=REAL_PER_CLASS, dist_opt=args.metric_name, device=dev,
               seed=1234, image_syn=syn, classes=my_classes)
     if args.path == "dropin":
@@ -107,7 +113,7 @@ def main():
     timer.install()
 
     def sync_all():
-        if world > 1:
+        if torch.distributed.is_initialized():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -171,7 +177,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(images_all, indices_class, net, syn, args)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -24,11 +24,12 @@ __host__ __device__ __forceinline__ int chunk3(int M) {
 }
 __host__ __device__ __forceinline__ int chunk128(int M) {
     int ch = (((M > 0 ? M : 1) + 255) / 256 + 31) / 32 * 32;
-    return ch < 512 ? 512 : ch;
+    const int lo = M >= 65536 ? 512 : 128;  // small launches (a synthetic batch, one class per GPU) need many short chunks to fill the CUs
+    return ch < lo ? lo : ch;
 }
 // slots needed for ANY row count <= bound: the chunk size is smallest (64 / 512) when there are few rows
 inline int64_t max_slots3(int64_t bound, int G) { return ceil_div64(bound, 64) < 512 + G ? ceil_div64(bound, 64) + G : 512 + G; }
-inline int64_t max_slots128(int64_t bound, int G) { return ceil_div64(bound, 512) < 256 + G ? ceil_div64(bound, 512) + G : 256 + G; }
+inline int64_t max_slots128(int64_t bound, int G) { return ceil_div64(bound, 128) < 512 + G ? ceil_div64(bound, 128) + G : 512 + G; }
 
 // ---------------------------------------------------------------------------------------------
 // Cin = Cout = 128 forward / backward-data

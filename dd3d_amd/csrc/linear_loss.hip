@@ -18,75 +18,88 @@ struct WStride {
     int64_t g, j, c, s;
 };
 
-// one workgroup per cloud; wave w takes voxels w, w+4, ...: the voxel's 128 features sit in the wave (float2 per lane) and are
-// multiplied into per-lane partial sums for up to 16 outputs at a time (16 independent 512-B weight rows in flight per voxel);
-// the 64-lane reductions happen once per output after the voxel loop, not per voxel.
-__global__ __launch_bounds__(256) void k_sl_fwd(const float* __restrict__ F, const int* __restrict__ site, const int* __restrict__ seg_off,
-                                                const int* __restrict__ cloud_group, const float* __restrict__ Wl, WStride ws, int J,
-                                                const float* __restrict__ bias, float* __restrict__ out) {
-    __shared__ float s_part[4][16];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int r0 = seg_off[b], r1 = seg_off[b + 1];
-    const int g = cloud_group ? cloud_group[b] : 0;
-    const float* Wg = Wl + g * ws.g;
+// Forward in two short launches instead of one long per-cloud loop (a cloud's voxels were walked serially, one dependent
+// site -> weight-row round trip each): (1) one WAVE per voxel -- its 128 features sit in the wave (float2 per lane) and are
+// multiplied into the J outputs' 512-B weight rows, 64-lane reductions give part[v][j]; (2) one thread per (cloud, output) adds the
+// cloud's voxels in row order (+ bias): deterministic.
+__global__ __launch_bounds__(256) void k_sl_fwd_part(const float* __restrict__ F, const int* __restrict__ site, const int4* __restrict__ coords,
+                                                     const int* __restrict__ m_ptr, const int* __restrict__ cloud_group, const float* __restrict__ Wl,
+                                                     WStride ws, int J, float* __restrict__ part) {
+    const int lane = threadIdx.x & 63;
+    const int M = *m_ptr;
+    // grid-stride over the voxels: the launch is sized for the chip, not for the bound (a bound-sized grid of 4-voxel workgroups
+    // would spend its time dispatching empty workgroups)
+    for (int v = blockIdx.x * 4 + (threadIdx.x >> 6); v < M; v += gridDim.x * 4) {
+    const int s = site[v];
+    float* out = part + (int64_t)v * J;
+    if (s < 0) {
+        if (lane < J) out[lane] = 0.f;
+        for (int j = 64 + lane; j < J; j += 64) out[j] = 0.f;
+        continue;
+    }
+    const int g = cloud_group ? cloud_group[coords[v].x] : 0;
+    const float2 f = *(const float2*)(F + (int64_t)v * 128 + lane * 2);
+    const float* Ws = Wl + g * ws.g + s * ws.s;
     const bool unit_c = ws.c == 1;
     for (int j0 = 0; j0 < J; j0 += 16) {
-        const int jn = min(16, J - j0);
         float acc[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) acc[u] = 0.f;
-        for (int v = r0 + wid; v < r1; v += 4) {
-            const int s = site[v];
-            if (s < 0) continue;
-            const float2 f = *(const float2*)(F + (int64_t)v * 128 + lane * 2);
-            const float* Ws = Wg + s * ws.s + (int64_t)j0 * ws.j;
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                if (u < jn) {
-                    const float* Wj = Ws + (int64_t)u * ws.j;
-                    float w0, w1;
-                    if (unit_c) {
-                        float2 w = *(const float2*)(Wj + lane * 2);
-                        w0 = w.x; w1 = w.y;
-                    } else {
-                        w0 = Wj[(int64_t)(lane * 2) * ws.c]; w1 = Wj[(int64_t)(lane * 2 + 1) * ws.c];
-                    }
-                    acc[u] += f.x * w0 + f.y * w1;
-                }
+        for (int u = 0; u < 16; ++u) {
+            const int j = min(j0 + u, J - 1);  // clamped: all 16 weight rows are loaded without a branch, extras are dropped below
+            const float* Wj = Ws + (int64_t)j * ws.j;
+            float w0, w1;
+            if (unit_c) {
+                const float2 w = *(const float2*)(Wj + lane * 2);
+                w0 = w.x; w1 = w.y;
+            } else {
+                w0 = Wj[(int64_t)(lane * 2) * ws.c]; w1 = Wj[(int64_t)(lane * 2 + 1) * ws.c];
             }
+            acc[u] = f.x * w0 + f.y * w1;
         }
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-            float t = wave_sum(acc[u]);
-            if (lane == u) s_part[wid][u] = t;
+            const float t = wave_sum(acc[u]);
+            if (lane == u && j0 + u < J) out[j0 + u] = t;
         }
-        __syncthreads();
-        if (tid < jn) {
-            float s = s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid];
-            if (bias) s += bias[j0 + tid];
-            out[(int64_t)b * J + j0 + tid] = s;
-        }
-        __syncthreads();
+    }
     }
 }
 
-__global__ __launch_bounds__(256) void k_sl_bwd_x(const float* __restrict__ dl, const int* __restrict__ site, const int* __restrict__ seg_off,
-                                                  const int* __restrict__ cloud_group, const float* __restrict__ Wl, WStride ws, int J,
-                                                  int accumulate, float* __restrict__ dF) {
-    extern __shared__ float s_dl[];
-    const int b = blockIdx.x, tid = threadIdx.x, c = tid & 127, rl = tid >> 7;
-    const int r0 = seg_off[b], r1 = seg_off[b + 1];
+__global__ void k_sl_fwd_sum(const float* __restrict__ part, const int* __restrict__ seg_off, int B, int J, const float* __restrict__ bias,
+                             float* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * J) return;
+    const int b = t / J, j = t - b * J;
+    float s = 0.f;
+    for (int v = seg_off[b]; v < seg_off[b + 1]; ++v) s += part[(int64_t)v * J + j];
+    out[t] = bias ? s + bias[j] : s;
+}
+
+// dF[v][c] = sum_j dl[b(v)][j] * Wl[g][j][c][s(v)]: every voxel is independent -> grid over voxels (2 per workgroup, 128 channel lanes)
+__global__ __launch_bounds__(256) void k_sl_bwd_x(const float* __restrict__ dl, const int* __restrict__ site, const int4* __restrict__ coords,
+                                                  const int* __restrict__ m_ptr, const int* __restrict__ cloud_group, const float* __restrict__ Wl,
+                                                  WStride ws, int J, int accumulate, float* __restrict__ dF) {
+    const int c = threadIdx.x & 127;
+    const int M = *m_ptr;
+    for (int v = blockIdx.x * 2 + (threadIdx.x >> 7); v < M; v += gridDim.x * 2) {  // grid-stride: see k_sl_fwd_part
+    const int s = site[v];
+    const int b = coords[v].x;
     const int g = cloud_group ? cloud_group[b] : 0;
-    for (int j = tid; j < J; j += 256) s_dl[j] = dl[(int64_t)b * J + j];
-    __syncthreads();
-    const float* Wg = Wl + g * ws.g + c * ws.c;
-    for (int v = r0 + rl; v < r1; v += 2) {
-        int s = site[v];
-        float acc = 0.f;
-        if (s >= 0)
-            for (int j = 0; j < J; ++j) acc += s_dl[j] * Wg[(int64_t)j * ws.j + s * ws.s];
-        int64_t o = (int64_t)v * 128 + c;
-        dF[o] = accumulate ? dF[o] + acc : acc;
+    float acc = 0.f;
+    if (s >= 0) {
+        const float* Wg = Wl + g * ws.g + c * ws.c + s * ws.s;
+        const float* d = dl + (int64_t)b * J;
+        for (int j0 = 0; j0 < J; j0 += 16) {
+            float w[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) w[u] = Wg[(int64_t)min(j0 + u, J - 1) * ws.j];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (j0 + u < J) acc += d[j0 + u] * w[u];
+        }
+    }
+    const int64_t o = (int64_t)v * 128 + c;
+    dF[o] = accumulate ? dF[o] + acc : acc;
     }
 }
 
@@ -303,7 +316,7 @@ __device__ __forceinline__ float row_term(int metric, float4 st) {
     return st.w;
 }
 
-// one block: per-row stats in chunk order, then the loss in (segment,row) order -> fully deterministic
+// one block per group: per-row stats in chunk order, then the loss as a fixed pairwise tree over the rows -> fully deterministic
 __global__ __launch_bounds__(256) void k_gd_finalize(const GPlan p, const float4* __restrict__ partial, float4* __restrict__ stats,
                                                      float* __restrict__ loss) {
     __shared__ float s_term[256];
@@ -335,12 +348,19 @@ __global__ __launch_bounds__(256) void k_gd_finalize(const GPlan p, const float4
         s_term[tid] = term;
         s_tot[tid] = st;
         __syncthreads();
-        if (tid == 0) {
-            int n = min(256, total_rows - base);
-            for (int i = 0; i < n; ++i) {
-                run += s_term[i];
-                tot.x += s_tot[i].x; tot.y += s_tot[i].y; tot.z += s_tot[i].z; tot.w += s_tot[i].w;
+        // fixed pairwise tree over the 256 slots (rows beyond total_rows hold zeros): deterministic, 8 short steps instead of a
+        // 256-long serial chain on one thread
+        for (int off = 128; off > 0; off >>= 1) {
+            if (tid < off) {
+                s_term[tid] += s_term[tid + off];
+                float4 a = s_tot[tid], b = s_tot[tid + off];
+                s_tot[tid] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
             }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            run += s_term[0];
+            tot.x += s_tot[0].x; tot.y += s_tot[0].y; tot.z += s_tot[0].z; tot.w += s_tot[0].w;
         }
         __syncthreads();
     }
@@ -452,23 +472,34 @@ int build_plan(const dd3d_gseg* segs, int n, int metric, GPlan* p) {
 
 static WStride mk_stride(const int64_t* st) { return WStride{st[0], st[1], st[2], st[3]}; }
 
-// strides[4] = element strides of Wl over (group, j, channel, site)
-DD3D_API int dd3d_sparse_linear_fwd(const float* F, const int32_t* site, const int32_t* seg_off, int B, int C, const int32_t* cloud_group,
-                                    const float* Wl, const int64_t* strides, int J, const float* bias, float* out, void* stream) {
-    if (B < 0 || C != 128 || J <= 0 || !strides) return DD3D_EARG;
+// strides[4] = element strides of Wl over (group, j, channel, site).  coords = int32 [M,4] rows of the voxels (column 0 = cloud),
+// M_bound rows at most; the true count is seg_off[B] (read on the device).  ws: dd3d_sparse_linear_ws_bytes(M_bound, J).
+DD3D_API int64_t dd3d_sparse_linear_ws_bytes(int64_t M_bound, int J) { return align_up64((M_bound > 0 ? M_bound : 1) * (int64_t)J * 4, 256); }
+
+DD3D_API int dd3d_sparse_linear_fwd(const float* F, const int32_t* site, const int32_t* coords, int64_t M_bound, const int32_t* seg_off, int B, int C,
+                                    const int32_t* cloud_group, const float* Wl, const int64_t* strides, int J, const float* bias, float* out, void* ws,
+                                    int64_t ws_bytes, void* stream) {
+    if (B < 0 || C != 128 || J <= 0 || M_bound < 0 || !strides) return DD3D_EARG;
     if (B == 0) return 0;
-    if (!F || !site || !seg_off || !Wl || !out) return DD3D_EARG;
-    k_sl_fwd<<<dim3(B), 256, 0, (hipStream_t)stream>>>(F, site, seg_off, cloud_group, Wl, mk_stride(strides), J, bias, out);
+    if (!F || !site || !coords || !seg_off || !Wl || !out) return DD3D_EARG;
+    if (!ws || ws_bytes < dd3d_sparse_linear_ws_bytes(M_bound, J)) return DD3D_EWS;
+    hipStream_t st = (hipStream_t)stream;
+    if (M_bound > 0)
+        k_sl_fwd_part<<<dim3((unsigned)(ceil_div64(M_bound, 4) < 4096 ? ceil_div64(M_bound, 4) : 4096)), 256, 0, st>>>(F, site, (const int4*)coords, seg_off + B, cloud_group, Wl, mk_stride(strides),
+                                                                             J, (float*)ws);
+    k_sl_fwd_sum<<<dim3((unsigned)ceil_div64((int64_t)B * J, 256)), 256, 0, st>>>((const float*)ws, seg_off, B, J, bias, out);
     DD3D_CHECK_LAUNCH();
     return 0;
 }
 
-DD3D_API int dd3d_sparse_linear_bwd_x(const float* dl, const int32_t* site, const int32_t* seg_off, int B, int C, const int32_t* cloud_group,
-                                      const float* Wl, const int64_t* strides, int J, int accumulate, float* dF, void* stream) {
-    if (B < 0 || C != 128 || J <= 0 || J > 8192 || !strides) return DD3D_EARG;
-    if (B == 0) return 0;
-    if (!dl || !site || !seg_off || !Wl || !dF) return DD3D_EARG;
-    k_sl_bwd_x<<<dim3(B), 256, J * sizeof(float), (hipStream_t)stream>>>(dl, site, seg_off, cloud_group, Wl, mk_stride(strides), J, accumulate, dF);
+DD3D_API int dd3d_sparse_linear_bwd_x(const float* dl, const int32_t* site, const int32_t* coords, int64_t M_bound, const int32_t* seg_off, int B, int C,
+                                      const int32_t* cloud_group, const float* Wl, const int64_t* strides, int J, int accumulate, float* dF,
+                                      void* stream) {
+    if (B < 0 || C != 128 || J <= 0 || M_bound < 0 || !strides) return DD3D_EARG;
+    if (B == 0 || M_bound == 0) return 0;
+    if (!dl || !site || !coords || !seg_off || !Wl || !dF) return DD3D_EARG;
+    k_sl_bwd_x<<<dim3((unsigned)(ceil_div64(M_bound, 2) < 8192 ? ceil_div64(M_bound, 2) : 8192)), 256, 0, (hipStream_t)stream>>>(dl, site, (const int4*)coords, seg_off + B, cloud_group, Wl,
+                                                                                       mk_stride(strides), J, accumulate, dF);
     DD3D_CHECK_LAUNCH();
     return 0;
 }

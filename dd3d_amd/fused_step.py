@@ -25,7 +25,7 @@ import torch
 
 from . import _lib as L
 from .distillation_loss import _METRICS, _rows_cols
-from .ops import DensePlacement, _site_strides, transposed_kernel
+from .ops import DensePlacement, _site_strides, sl_bwd_x_call, sl_fwd_call, transposed_kernel
 from .sparse import CloudCoordinateManager, CoordinateManager
 from .utils.Mnist2D import batch_from_images
 
@@ -111,8 +111,7 @@ class _Pass:
         P1, arg1 = self.P1, self.arg1 = _empty((M2, 128), dev), _empty((M2, 128), dev, _I32)
         L.call("dd3d_affine_relu_pool_fwd", L.ptr(xh1), L.ptr(w5), L.ptr(b5), 1, 128, L.ptr(p1), pl1, 8, M2, c2, L.ptr(P1), L.ptr(arg1), st)
         logits = self.logits = _empty((B, J), dev)
-        L.call("dd3d_sparse_linear_fwd", L.ptr(P1), L.ptr(dp.site), L.ptr(dp.seg_off), B, 128, None, L.ptr(Wsm), sst, J, L.ptr(cls_b),
-               L.ptr(logits), st)
+        sl_fwd_call(P1, dp, None, Wsm, sst, J, cls_b, logits)
         prob, dl = self.prob, self.dl = _empty((B, J), dev), _empty((B, J), dev)
         closs, self.ce = _empty((B,), dev), _empty((G,), dev)
         L.call("dd3d_softmax_ce", L.ptr(logits), L.ptr(labels), L.ptr(cloud_group), L.ptr(group_cloud_off), G, B, J, L.ptr(prob), L.ptr(dl),
@@ -126,7 +125,7 @@ class _Pass:
         L.call("dd3d_sparse_linear_bwd_w", L.ptr(dl), L.ptr(P1), L.ptr(dp.vox_at), S, B, L.ptr(group_cloud_off), G, 128, J, L.ptr(g_cw), pst,
                g_cw.numel(), st)
         gP1 = _empty((M2, 128), dev)
-        L.call("dd3d_sparse_linear_bwd_x", L.ptr(dl), L.ptr(dp.site), L.ptr(dp.seg_off), B, 128, None, L.ptr(Wsm), sst, J, 0, L.ptr(gP1), st)
+        sl_bwd_x_call(dl, dp, None, Wsm, sst, J, 0, gP1)
         gY1, self.ga1, g_w5, g_b5 = self._arp_inorm_bwd(gP1, arg1, cm.parent(4), xh1, is1, w5, b5, seg2, M1, keep_ga, True)
         g_W1 = self._bww(P0, 128, gY1, k1, ld1, M1, gro2)
         gP0 = _empty((M1, 128), dev)
@@ -171,16 +170,14 @@ class _Pass:
         L.call("dd3d_classifier_layout", L.ptr(G_cw), G, J, 128, S, 0, L.ptr(Gsm), st)
         # u = dL/d(dlogits): through gw[W] = dlogits^T dense and gw[b] = sum dlogits
         u = _empty((B, J), dev)
-        L.call("dd3d_sparse_linear_fwd", L.ptr(self.P1), L.ptr(dp.site), L.ptr(dp.seg_off), B, 128, L.ptr(self.cloud_group), L.ptr(Gsm), sst, J,
-               None, L.ptr(u), st)
+        sl_fwd_call(self.P1, dp, self.cloud_group, Gsm, sst, J, None, u)
         dz = _empty((B, J), dev)
         per = int((self.gco[1:] - self.gco[:-1]).max().item()) if self._max_per is None else self._max_per
         L.call("dd3d_softmax_ce_bwd2", L.ptr(self.prob), L.ptr(u), L.ptr(G_cb), L.ptr(self.gco), G, J, per, L.ptr(dz), st)
         # H = dL/dP1: through dense in gw[W] (weights G_cw, coefficients dlogits) and through the logits (weights W, coefficients dz)
         H = _empty((M2, 128), dev)
-        L.call("dd3d_sparse_linear_bwd_x", L.ptr(self.dl), L.ptr(dp.site), L.ptr(dp.seg_off), B, 128, L.ptr(self.cloud_group), L.ptr(Gsm), sst, J,
-               0, L.ptr(H), st)
-        L.call("dd3d_sparse_linear_bwd_x", L.ptr(dz), L.ptr(dp.site), L.ptr(dp.seg_off), B, 128, None, L.ptr(self.Wsm), sst, J, 1, L.ptr(H), st)
+        sl_bwd_x_call(self.dl, dp, self.cloud_group, Gsm, sst, J, 0, H)
+        sl_bwd_x_call(dz, dp, None, self.Wsm, sst, J, 1, H)
         hY1, _, _, _ = self._arp_inorm_bwd(H, self.arg1, cm.parent(4), self.xh1, self.is1, w5, b5, seg2, M1, False, False, self.ga1, G_w5)
         hP0 = _empty((M1, 128), dev)
         L.call("dd3d_conv_bwd_data", L.ptr(hY1), M1, self.cnt[1], 128, L.ptr(self.W1t), 128, L.ptr(k1), ld1, 27, L.ptr(hP0), st)
@@ -429,7 +426,9 @@ class FusedDistiller:
             else:
                 if self._graph is None:
                     self._graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self._graph):
+                    # thread_local: only this thread's calls are checked during capture (an RCCL watchdog thread polling its events
+                    # must not invalidate it)
+                    with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
                         self._graph_loss = self._static_body()
                     self._graph_last = self.last
                 self._graph.replay()

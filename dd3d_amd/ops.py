@@ -248,6 +248,7 @@ class DensePlacement:
         self.cloud_group = cloud_group
         self.group_cloud_off = group_cloud_off if group_cloud_off is not None else torch.tensor([0, self.B], dtype=torch.int32, device=dev)
         self.seg_off = cm.seg_off(stride)
+        self.C, self.M_bound = lv.C, max(cm._rows_bound(lv), 1)   # voxel rows (column 0 = cloud) and their bound
         pre = getattr(cm, "dense_tables", None)
         if pre is not None and stride == 4 and pre[0] == self.E and pre[1] is cloud_group:
             _, _, self.gmin, self.site, self.vox_at = pre     # the cloud-local map builder already placed the voxels
@@ -259,6 +260,19 @@ class DensePlacement:
         L.call("dd3d_dense_sites", L.ptr(lv.C), cm._count_ptr(lv), bound, L.ptr(cloud_group), G, self.B, stride, self.E[0], self.E[1], self.E[2],
                L.ptr(self.gmin), L.ptr(self.site), L.ptr(self.vox_at), L.ptr(cm.err), L.stream())
         cm._synced = False
+
+
+def sl_fwd_call(F, dp, cloud_group, Wl, strides, J, bias, out):
+    """dd3d_sparse_linear_fwd on raw buffers: out[B,J] = sum over each cloud's voxels of F[v] . Wl[group][.,.,site(v)] (+ bias)."""
+    ws = L.workspace(int(L.lib.dd3d_sparse_linear_ws_bytes(dp.M_bound, J)), F.device)
+    L.call("dd3d_sparse_linear_fwd", L.ptr(F), L.ptr(dp.site), L.ptr(dp.C), dp.M_bound, L.ptr(dp.seg_off), dp.B, 128, L.ptr(cloud_group), L.ptr(Wl),
+           strides, J, L.ptr(bias), L.ptr(out), L.ptr(ws), ws.numel(), L.stream())
+
+
+def sl_bwd_x_call(dl, dp, cloud_group, Wl, strides, J, accumulate, dF):
+    """dd3d_sparse_linear_bwd_x on raw buffers: dF[v] (+)= sum_j dl[cloud(v)][j] * Wl[group][j][., site(v)]."""
+    L.call("dd3d_sparse_linear_bwd_x", L.ptr(dl), L.ptr(dp.site), L.ptr(dp.C), dp.M_bound, L.ptr(dp.seg_off), dp.B, 128, L.ptr(cloud_group), L.ptr(Wl),
+           strides, J, int(accumulate), L.ptr(dF), L.stream())
 
 
 def _param_strides(J, C, S):
@@ -297,8 +311,7 @@ class _SLFwd(Function):
         w = site_major(Wl, f.shape[1], dp.S)
         J = w.shape[-2]
         out = torch.empty((dp.B, J), dtype=_F32, device=f.device)
-        L.call("dd3d_sparse_linear_fwd", L.ptr(f), L.ptr(dp.site), L.ptr(dp.seg_off), dp.B, f.shape[1], L.ptr(dp.cloud_group if w.dim() == 3 else None),
-               L.ptr(w), _site_strides(J, f.shape[1], dp.S), J, None, L.ptr(out), L.stream())
+        sl_fwd_call(f, dp, dp.cloud_group if w.dim() == 3 else None, w, _site_strides(J, f.shape[1], dp.S), J, None, out)
         ctx.save_for_backward(F, Wl)
         ctx.dp = dp
         return out
@@ -319,8 +332,7 @@ class _SLBwdX(Function):
         J = d.shape[1]
         M = int(dp.seg_off_rows)
         dF = torch.empty((M, 128), dtype=_F32, device=d.device)
-        L.call("dd3d_sparse_linear_bwd_x", L.ptr(d), L.ptr(dp.site), L.ptr(dp.seg_off), dp.B, 128, L.ptr(dp.cloud_group if w.dim() == 3 else None),
-               L.ptr(w), _site_strides(J, 128, dp.S), J, 0, L.ptr(dF), L.stream())
+        sl_bwd_x_call(d, dp, dp.cloud_group if w.dim() == 3 else None, w, _site_strides(J, 128, dp.S), J, 0, dF)
         ctx.save_for_backward(dl, Wl)
         ctx.dp = dp
         return dF

@@ -18,7 +18,7 @@ def owned_classes(num_classes: int, rank: int, world: int) -> List[int]:
 
 
 def is_distributed() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized()
 
 
 def reduce_loss(loss: torch.Tensor) -> torch.Tensor:

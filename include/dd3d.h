@@ -174,10 +174,14 @@ int dd3d_scale_rows_by_group(const float* ga, const float* gw, const int32_t* gr
  * replaces: SparseTensor.dense() + view(-1,100352) + nn.Linear(100352,10) and their autograd, models/MEConv.py:254-256
  * strides[4] (HOST) = element strides of the weight-like operand over (group, output j, channel c, site s)
  * ------------------------------------------------------------------------------------------------------------------- */
-int dd3d_sparse_linear_fwd(const float* F, const int32_t* site, const int32_t* seg_off, int B, int C, const int32_t* cloud_group, const float* Wl,
-                           const int64_t* strides, int J, const float* bias, float* out, void* stream);
-int dd3d_sparse_linear_bwd_x(const float* dl, const int32_t* site, const int32_t* seg_off, int B, int C, const int32_t* cloud_group, const float* Wl,
-                             const int64_t* strides, int J, int accumulate, float* dF, void* stream);
+/* coords = int32 [M,4] voxel rows (column 0 = cloud index), M_bound = their bound; the true row count is seg_off[B] (device).
+ * fwd runs as per-voxel partial products (one wave per voxel) + an ordered per-cloud sum: ws from dd3d_sparse_linear_ws_bytes. */
+int64_t dd3d_sparse_linear_ws_bytes(int64_t M_bound, int J);
+int dd3d_sparse_linear_fwd(const float* F, const int32_t* site, const int32_t* coords, int64_t M_bound, const int32_t* seg_off, int B, int C,
+                           const int32_t* cloud_group, const float* Wl, const int64_t* strides, int J, const float* bias, float* out, void* ws,
+                           int64_t ws_bytes, void* stream);
+int dd3d_sparse_linear_bwd_x(const float* dl, const int32_t* site, const int32_t* coords, int64_t M_bound, const int32_t* seg_off, int B, int C,
+                             const int32_t* cloud_group, const float* Wl, const int64_t* strides, int J, int accumulate, float* dF, void* stream);
 int dd3d_sparse_linear_bwd_w(const float* dl, const float* F, const int32_t* vox_at, int S, int B, const int32_t* group_cloud_off, int G, int C, int J,
                              float* dWl, const int64_t* strides, int64_t dWl_elems, void* stream);
 

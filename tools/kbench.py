@@ -5,7 +5,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dd3d_amd import _lib as L
 from dd3d_amd.sparse import CoordinateManager
-from dd3d_amd.ops import DensePlacement, site_major, _site_strides
+from dd3d_amd.ops import DensePlacement, site_major, _site_strides, sl_fwd_call, sl_bwd_x_call
 from dd3d_amd.synthetic import mnist3d_like
 from dd3d_amd.utils.Mnist2D import batch_from_images
 
@@ -54,8 +54,8 @@ K = {
  "conv128_fwd": (lambda: L.call("dd3d_conv_fwd", L.ptr(P0), M1, 128, L.ptr(W1), 128, L.ptr(k1), ld1, 27, M1, None, 0, L.ptr(Y1), st), 0),
  "inorm_fwd L2": (lambda: L.call("dd3d_inorm_fwd", L.ptr(Y1), L.ptr(seg2), B, 128, L.ptr(xh1), L.ptr(is1), st), 1024 * M1),
  "arp_fwd L2": (lambda: L.call("dd3d_affine_relu_pool_fwd", L.ptr(xh1), L.ptr(w), L.ptr(bb), 1, 128, L.ptr(p1), pl1, 8, M2, None, L.ptr(P1), L.ptr(arg1), st), 512 * M1 + 1024 * M2),
- "sl_fwd": (lambda: L.call("dd3d_sparse_linear_fwd", L.ptr(P1), L.ptr(dp.site), L.ptr(dp.seg_off), B, 128, None, L.ptr(Wsm), sst, J, None, L.ptr(logits), st), 512 * M2 * (1 + J)),
- "sl_bwd_x": (lambda: L.call("dd3d_sparse_linear_bwd_x", L.ptr(dl), L.ptr(dp.site), L.ptr(dp.seg_off), B, 128, None, L.ptr(Wsm), sst, J, 0, L.ptr(P1), st), 512 * M2 * (1 + J)),
+ "sl_fwd": (lambda: sl_fwd_call(P1, dp, None, Wsm, sst, J, None, logits), 512 * M2 * (1 + J)),
+ "sl_bwd_x": (lambda: sl_bwd_x_call(dl, dp, None, Wsm, sst, J, 0, P1), 512 * M2 * (1 + J)),
  "arp_inorm_bwd L1": (lambda: L.call("dd3d_arp_inorm_bwd", L.ptr(gP0), L.ptr(arg0), L.ptr(cm.parent(2)), L.ptr(xh0), L.ptr(is0), L.ptr(w), L.ptr(bb), 128, L.ptr(seg1), B,
                                      L.ptr(cg), L.ptr(gco), G, L.ptr(gY0), None, None, None, L.ptr(gw_w), L.ptr(gw_b), L.ptr(ws), ws.numel(), st), 1024 * M0 + 1024 * M1),
  "conv128_bww": (lambda: L.call("dd3d_conv_bwd_weight", L.ptr(P0), 128, L.ptr(gY1), 128, L.ptr(k1), ld1, 27, M1, L.ptr(gro2), G, L.ptr(dW1), L.ptr(ws), ws.numel(), st), 0),
