@@ -61,6 +61,16 @@ K = {
  "conv128_bww": (lambda: L.call("dd3d_conv_bwd_weight", L.ptr(P0), 128, L.ptr(gY1), 128, L.ptr(k1), ld1, 27, M1, L.ptr(gro2), G, L.ptr(dW1), L.ptr(ws), ws.numel(), st), 0),
  "conv3_bww": (lambda: L.call("dd3d_conv_bwd_weight", L.ptr(F0), 3, L.ptr(gY0), 128, L.ptr(k0), ld0, 27, M0, L.ptr(gro1), G, L.ptr(dW0), L.ptr(ws), ws.numel(), st), 512 * M0 + 120 * M0),
 }
+from dd3d_amd.sparse import CloudCoordinateManager
+from dd3d_amd.synthetic import init_synthetic
+_syn = init_synthetic(10, 10, 250, seed=0).to(dev).clamp_(0, 27)
+_syn[:, :, 0] = 0
+_sc = torch.cat([torch.arange(100, device=dev, dtype=torch.float32).repeat_interleave(250)[:, None], _syn.reshape(-1, 3)], 1).contiguous()
+_spt = (torch.arange(101, device=dev) * 250).to(torch.int32)
+_scg = torch.arange(10, device=dev, dtype=torch.int32).repeat_interleave(10)
+_sgco = (torch.arange(11, device=dev) * 10).to(torch.int32)
+K["cloud_maps real (2560 clouds)"] = (lambda: CloudCoordinateManager(b["coordinates"], b["pt_off"], B, 250, (1, 28, 28), cg, G, gco), 0)
+K["cloud_maps syn (100 clouds)"] = (lambda: CloudCoordinateManager(_sc, _spt, 100, 250, (1, 28, 28), _scg, 10, _sgco), 0)
 # forward chain once so that arg/xhat hold sane values
 for k in ("conv3_fwd", "inorm_fwd L1", "arp_fwd L1", "conv128_fwd", "inorm_fwd L2", "arp_fwd L2"):
     K[k][0]()
@@ -77,5 +87,5 @@ for name, (fn, nbytes) in K.items():
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / n * 1e3
-    extra = f"{nbytes / us / 1e6:6.2f} TB/s (alg bytes)" if nbytes else f"{2 * pairs1 * 128 * 128 / us / 1e6:6.1f} TFLOP/s (alg)"
+    extra = f"{nbytes / us / 1e6:6.2f} TB/s (alg bytes)" if nbytes else (f"{2 * pairs1 * 128 * 128 / us / 1e6:6.1f} TFLOP/s (alg)" if "conv128" in name else "")
     print(f"{name:24s} {us:8.1f} us   {extra}")
