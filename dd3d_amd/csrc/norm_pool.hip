@@ -293,13 +293,15 @@ __global__ __launch_bounds__(RL * CL) void k_arp_inorm_bwd(const f32x4* __restri
                                                            const f32x4* __restrict__ xhat, const f32x4* __restrict__ inv_std,
                                                            const f32x4* __restrict__ w, const f32x4* __restrict__ bias,
                                                            const int* __restrict__ seg_off, const int* __restrict__ cloud_group,
-                                                           f32x4* __restrict__ dY, f32x4* __restrict__ ga_out, const f32x4* __restrict__ ga_prev,
-                                                           const f32x4* __restrict__ gw_extra, f32x4* __restrict__ part /*[B][2][32] or null*/) {
+                                                           f32x4* __restrict__ dY, f32x4* __restrict__ ga_out_all, int ga_clouds,
+                                                           const f32x4* __restrict__ ga_prev, const f32x4* __restrict__ gw_extra,
+                                                           f32x4* __restrict__ part /*[B][2][32] or null*/) {
     __shared__ f32x4 s_red[RL * CL];
     const int b = blockIdx.x, c4 = blockIdx.y * CL + threadIdx.x % CL, rl = threadIdx.x / CL;
     const int r0 = seg_off[b], r1 = seg_off[b + 1];
     const int n = r1 - r0;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4* ga_out = (ga_clouds <= 0 || b < ga_clouds) ? ga_out_all : nullptr;  // only the leading clouds keep their masked gradient
     if (n <= 0) {
         if (part && rl == 0) {
             part[((int64_t)b * 2 + 0) * 32 + c4] = zero;
@@ -500,8 +502,8 @@ DD3D_API int64_t dd3d_arp_inorm_bwd_ws_bytes(int B) { return align_up64((int64_t
 // ga_prev + gw_extra[G,128] (nullable pair): adds ga_prev * gw_extra[group] to the gradient w.r.t. xhat first.
 DD3D_API int dd3d_arp_inorm_bwd(const float* g_pool, const int32_t* arg, const int32_t* parent, const float* xhat, const float* inv_std,
                                 const float* w, const float* b, int C, const int32_t* seg_off, int B, const int32_t* cloud_group,
-                                const int32_t* group_cloud_off, int G, float* dY, float* ga_out, const float* ga_prev, const float* gw_extra,
-                                float* gw_w, float* gw_b, void* ws, int64_t ws_bytes, void* stream) {
+                                const int32_t* group_cloud_off, int G, float* dY, float* ga_out, int ga_clouds, const float* ga_prev,
+                                const float* gw_extra, float* gw_w, float* gw_b, void* ws, int64_t ws_bytes, void* stream) {
     if (B < 0 || C != 128 || G <= 0 || !w || !b || ((ga_prev == nullptr) != (gw_extra == nullptr)) || ((gw_w == nullptr) != (gw_b == nullptr)) ||
         (gw_w && !group_cloud_off) || (G > 1 && gw_extra && !cloud_group))
         return DD3D_EARG;
@@ -510,7 +512,7 @@ DD3D_API int dd3d_arp_inorm_bwd(const float* g_pool, const int32_t* arg, const i
     if (B > 0) {
         if (!g_pool || !arg || !parent || !xhat || !inv_std || !seg_off || !dY) return DD3D_EARG;
         k_arp_inorm_bwd<32, 4, 16><<<dim3(B, 2), 512, 0, st>>>((const f32x4*)g_pool, (const int4*)arg, parent, (const f32x4*)xhat, (const f32x4*)inv_std,
-                                                        (const f32x4*)w, (const f32x4*)b, seg_off, cloud_group, (f32x4*)dY, (f32x4*)ga_out,
+                                                        (const f32x4*)w, (const f32x4*)b, seg_off, cloud_group, (f32x4*)dY, (f32x4*)ga_out, ga_clouds,
                                                         (const f32x4*)ga_prev, (const f32x4*)gw_extra, gw_w ? (f32x4*)ws : nullptr);
     }
     if (gw_w) k_cloud_group_sum<<<dim3(G), 1024, 0, st>>>((const f32x4*)ws, group_cloud_off, (f32x4*)gw_w, (f32x4*)gw_b);

@@ -5,7 +5,8 @@ Why it exists (SURVEY.md section 7 "tiny problem, big GPU"): one class is ~7k vo
 64-row tiles for 256 CUs -- and the reference loop pays hundreds of launches plus three host syncs per class.  Classes are
 independent inside a step (mnist_distill.py:335), so a (class, cloud) batch index turns 10 small problems into one large one:
 the class of a cloud is its *group*; per-group reductions (kernel gradients, affine gradients, classifier gradients, the matching
-loss) come out of the same launches.  One device->host read per pass (row counts) is the only synchronisation.
+loss) come out of the same launches.  The synthetic and the real batch of every class share those launches too (groups g and
+G + g of one merged batch, synthetic clouds first), so a step is ONE chain of ~55 launches; in graph mode nothing is read back.
 
 The derivative structure is the reference's: first-order sparse kernels everywhere; the second-order terms
 are exactly those that torch autograd produces around MinkowskiEngine's opaque backward passes --
@@ -17,7 +18,6 @@ are exactly those that torch autograd produces around MinkowskiEngine's opaque b
 from __future__ import annotations
 
 import ctypes
-import os
 from typing import List, Optional
 
 import numpy as np
@@ -37,14 +37,21 @@ def _empty(shape, dev, dtype=_F32):
 
 
 class _Pass:
-    """Forward + first-order backward of MEConvExp over one class-batched set of clouds; keeps what the second-order pass needs."""
+    """Forward + first-order backward of MEConvExp over ONE class-batched set of clouds -- the synthetic clouds first, then the real
+    ones -- and the second-order backward over the synthetic prefix.
 
-    def __init__(self, net, coords, B, G, cloud_group, group_cloud_off, n_dev=None, static=False, pt_off=None, max_points=0):
-        """Phase 1 (no host sync): every coordinate map of the pass, enqueued on the current stream.
+    Both batches go through every kernel together: group g < Gs is the synthetic batch of class g, group Gs + g the real batch of the
+    same class, so the per-group reductions deliver gw_syn = gw[:Gs] and gw_real = gw[Gs:] from the same launches.  Because the
+    synthetic clouds come first, their points, voxel rows (at every stride) and clouds are PREFIXES of the arrays: the second-order
+    pass is the same kernels called on the first ``B_syn`` clouds with the prefix's row counts (``seg_off[B_syn]``, on the device)."""
+
+    def __init__(self, net, coords, B, G, cloud_group, group_cloud_off, B_syn, N_syn, n_dev=None, static=False, pt_off=None, max_points=0):
+        """Phase 1 (no host sync): every coordinate map, enqueued on the current stream.
         ``static``: never read a size back -- every launch covers its bound and takes the true row count from the device
         (``n_dev`` = number of valid rows of ``coords``), so the pass can be captured into a HIP graph."""
         dev = coords.device
         self.dev, self.B, self.G, self.net = dev, B, G, net
+        self.B_syn, self.N_syn, self.Gs = B_syn, N_syn, G // 2
         self.cloud_group, self.gco = cloud_group, group_cloud_off
         self.static = static
         if pt_off is not None and 0 < max_points <= int(L.lib.dd3d_cloud_maps_max_points()):
@@ -65,8 +72,8 @@ class _Pass:
             gro1, gro2 = seg1[gidx].contiguous(), seg2[gidx].contiguous()   # rows of every group at tensor strides 1 and 2
         self._pre = (k0, p0, k1, p1, seg1, seg2, gro1, gro2)
 
-    def run(self, feats, labels, keep_ga: bool):
-        """Phase 2: ONE device->host read (row counts), then forward + first-order backward on the current stream."""
+    def run(self, feats, labels):
+        """Phase 2: (eager mode: ONE device->host read of the row counts, then) forward + first-order backward on the current stream."""
         net, dev, B, G, cm, dp = self.net, self.dev, self.B, self.G, self.cm, self.dp
         cloud_group, group_cloud_off = self.cloud_group, self.gco
         (k0, ld0), (p0, pl0), (k1, ld1), (p1, pl1), seg1, seg2, gro1, gro2 = self._pre
@@ -126,28 +133,31 @@ class _Pass:
                g_cw.numel(), st)
         gP1 = _empty((M2, 128), dev)
         sl_bwd_x_call(dl, dp, None, Wsm, sst, J, 0, gP1)
-        gY1, self.ga1, g_w5, g_b5 = self._arp_inorm_bwd(gP1, arg1, cm.parent(4), xh1, is1, w5, b5, seg2, M1, keep_ga, True)
+        # the ReLU-masked pooled gradients (ga) are kept for the synthetic clouds only: the second-order pass needs nothing else
+        Ns = max(self.N_syn, 1)
+        self.ga1, self.ga0 = _empty((Ns, 128), dev), _empty((Ns, 128), dev)
+        gY1, g_w5, g_b5 = self._arp_inorm_bwd(gP1, arg1, cm.parent(4), xh1, is1, w5, b5, seg2, M1, B, G, self.ga1, self.B_syn, True)
         g_W1 = self._bww(P0, 128, gY1, k1, ld1, M1, gro2)
         gP0 = _empty((M1, 128), dev)
         L.call("dd3d_conv_bwd_data", L.ptr(gY1), M1, c1, 128, L.ptr(W1t), 128, L.ptr(k1), ld1, 27, L.ptr(gP0), st)
-        gY0, self.ga0, g_w1, g_b1 = self._arp_inorm_bwd(gP0, arg0, cm.parent(2), xh0, is0, w1, b1, seg1, M0, keep_ga, True)
+        gY0, g_w1, g_b1 = self._arp_inorm_bwd(gP0, arg0, cm.parent(2), xh0, is0, w1, b1, seg1, M0, B, G, self.ga0, self.B_syn, True)
         g_W0 = self._bww(F0, 3, gY0, k0, ld0, M0, gro1)
         # order of network.parameters()
         self.gw = [g_W0, g_w1, g_b1, g_W1, g_w5, g_b5, g_cw, g_cb]
         return self
 
-    def _arp_inorm_bwd(self, g_pool, arg, parent, xhat, inv_std, w, b, seg, M_in, keep_ga, want_gw, ga_prev=None, gw_extra=None):
-        """Backward of max-pool -> ReLU -> affine -> instance norm in one pass per cloud: (dY, ga, d weight [G,128], d bias [G,128])."""
-        dev, G, B = self.dev, self.G, self.B
+    def _arp_inorm_bwd(self, g_pool, arg, parent, xhat, inv_std, w, b, seg, M_in, B, G, ga_out, ga_clouds, want_gw, ga_prev=None, gw_extra=None):
+        """Backward of max-pool -> ReLU -> affine -> instance norm in one pass per cloud, over the first B clouds:
+        (dY, d weight [G,128], d bias [G,128]); ``ga_out`` receives the masked pooled gradient of the first ``ga_clouds`` clouds."""
+        dev = self.dev
         dY = _empty((M_in, 128), dev)
-        ga = _empty((M_in, 128), dev) if keep_ga else None
         gw_w = _empty((G, 128), dev) if want_gw else None
         gw_b = _empty((G, 128), dev) if want_gw else None
         ws = L.workspace(int(L.lib.dd3d_arp_inorm_bwd_ws_bytes(B)), dev)
         L.call("dd3d_arp_inorm_bwd", L.ptr(g_pool), L.ptr(arg), L.ptr(parent), L.ptr(xhat), L.ptr(inv_std), L.ptr(w), L.ptr(b), 128, L.ptr(seg), B,
-               L.ptr(self.cloud_group), L.ptr(self.gco), G, L.ptr(dY), L.ptr(ga), L.ptr(ga_prev), L.ptr(gw_extra), L.ptr(gw_w), L.ptr(gw_b),
-               L.ptr(ws), ws.numel(), L.stream())
-        return dY, ga, gw_w, gw_b
+               L.ptr(self.cloud_group), L.ptr(self.gco), G, L.ptr(dY), L.ptr(ga_out), int(ga_clouds), L.ptr(ga_prev), L.ptr(gw_extra), L.ptr(gw_w),
+               L.ptr(gw_b), L.ptr(ws), ws.numel(), L.stream())
+        return dY, gw_w, gw_b
 
     def _bww(self, X, Cin, dY, nbr, ld, M, gro):
         G = self.G
@@ -157,38 +167,37 @@ class _Pass:
                L.stream())
         return dW
 
-    # ---------------- second-order backward into the point features (synthetic pass only) ----------------
-    def backward_to_points(self, G_w1, G_w5, G_cw, G_cb):
-        """d(sum_g matching loss) / d feats [N,3], given its gradients w.r.t. the four differentiable entries of gw_syn."""
-        dev, B, G, J, S = self.dev, self.B, self.G, self.J, self.S
-        M0, M1, M2 = self.M
+    # ---------------- second-order backward into the synthetic points: the same kernels on the synthetic prefix ----------------
+    def backward_to_points(self, G_w1, G_w5, G_cw, G_cb, per):
+        """d(sum_g matching loss) / d feats [N_syn,3], given its gradients w.r.t. the four differentiable entries of gw_syn
+        (each [Gs, ...]).  ``per`` = clouds per synthetic group."""
+        dev, Bs, Gs, J, S, Ns = self.dev, self.B_syn, self.Gs, self.J, self.S, max(self.N_syn, 1)
         k0, ld0, p0, pl0, k1, ld1, p1, pl1, seg1, seg2, gro1, gro2 = self.maps
         W0, W1, w1, b1, w5, b5 = self.params
         dp, cm, st = self.dp, self.cm, L.stream()
+        # rows of the synthetic clouds at strides 1 / 2 (device-side counts; their bound is the number of synthetic points)
+        m1s, m2s = seg1[Bs:].data_ptr(), seg2[Bs:].data_ptr()
         sst = _site_strides(J, 128, S)
-        Gsm = _empty((G, S, J, 128), dev)
-        L.call("dd3d_classifier_layout", L.ptr(G_cw), G, J, 128, S, 0, L.ptr(Gsm), st)
-        # u = dL/d(dlogits): through gw[W] = dlogits^T dense and gw[b] = sum dlogits
-        u = _empty((B, J), dev)
-        sl_fwd_call(self.P1, dp, self.cloud_group, Gsm, sst, J, None, u)
-        dz = _empty((B, J), dev)
-        per = int((self.gco[1:] - self.gco[:-1]).max().item()) if self._max_per is None else self._max_per
-        L.call("dd3d_softmax_ce_bwd2", L.ptr(self.prob), L.ptr(u), L.ptr(G_cb), L.ptr(self.gco), G, J, per, L.ptr(dz), st)
+        Gsm = _empty((Gs, S, J, 128), dev)
+        L.call("dd3d_classifier_layout", L.ptr(G_cw), Gs, J, 128, S, 0, L.ptr(Gsm), st)
+        # u = dL/d(dlogits): through gw[W] = dlogits^T dense and gw[b] = sum dlogits (the latter is added inside softmax_ce_bwd2)
+        u = _empty((Bs, J), dev)
+        sl_fwd_call(self.P1, dp, self.cloud_group, Gsm, sst, J, None, u, Bs, Ns)
+        dz = _empty((Bs, J), dev)
+        L.call("dd3d_softmax_ce_bwd2", L.ptr(self.prob), L.ptr(u), L.ptr(G_cb), L.ptr(self.gco), Gs, J, per, L.ptr(dz), st)
         # H = dL/dP1: through dense in gw[W] (weights G_cw, coefficients dlogits) and through the logits (weights W, coefficients dz)
-        H = _empty((M2, 128), dev)
-        sl_bwd_x_call(self.dl, dp, self.cloud_group, Gsm, sst, J, 0, H)
-        sl_bwd_x_call(dz, dp, None, self.Wsm, sst, J, 1, H)
-        hY1, _, _, _ = self._arp_inorm_bwd(H, self.arg1, cm.parent(4), self.xh1, self.is1, w5, b5, seg2, M1, False, False, self.ga1, G_w5)
-        hP0 = _empty((M1, 128), dev)
-        L.call("dd3d_conv_bwd_data", L.ptr(hY1), M1, self.cnt[1], 128, L.ptr(self.W1t), 128, L.ptr(k1), ld1, 27, L.ptr(hP0), st)
-        hY0, _, _, _ = self._arp_inorm_bwd(hP0, self.arg0, cm.parent(2), self.xh0, self.is0, w1, b1, seg1, M0, False, False, self.ga0, G_w1)
-        hF0 = _empty((M0, 3), dev)
-        L.call("dd3d_conv_bwd_data", L.ptr(hY0), M0, self.cnt[0], 128, L.ptr(W0), 3, L.ptr(k0), ld0, 27, L.ptr(hF0), st)
-        dfeats = _empty((self.N, 3), dev)
-        L.call("dd3d_voxel_mean_bwd", L.ptr(hF0), M0, 3, L.ptr(cm.levels[1].inv), L.ptr(cm.vox_off), self.N, L.ptr(dfeats), st)
+        H = _empty((Ns, 128), dev)
+        sl_bwd_x_call(self.dl, dp, self.cloud_group, Gsm, sst, J, 0, H, Bs, Ns)
+        sl_bwd_x_call(dz, dp, None, self.Wsm, sst, J, 1, H, Bs, Ns)
+        hY1, _, _ = self._arp_inorm_bwd(H, self.arg1, cm.parent(4), self.xh1, self.is1, w5, b5, seg2, Ns, Bs, Gs, None, 0, False, self.ga1, G_w5)
+        hP0 = _empty((Ns, 128), dev)
+        L.call("dd3d_conv_bwd_data", L.ptr(hY1), Ns, m2s, 128, L.ptr(self.W1t), 128, L.ptr(k1), ld1, 27, L.ptr(hP0), st)
+        hY0, _, _ = self._arp_inorm_bwd(hP0, self.arg0, cm.parent(2), self.xh0, self.is0, w1, b1, seg1, Ns, Bs, Gs, None, 0, False, self.ga0, G_w1)
+        hF0 = _empty((Ns, 3), dev)
+        L.call("dd3d_conv_bwd_data", L.ptr(hY0), Ns, m1s, 128, L.ptr(W0), 3, L.ptr(k0), ld0, 27, L.ptr(hF0), st)
+        dfeats = _empty((Ns, 3), dev)
+        L.call("dd3d_voxel_mean_bwd", L.ptr(hF0), Ns, 3, L.ptr(cm.levels[1].inv), L.ptr(cm.vox_off), self.N_syn, L.ptr(dfeats), st)
         return dfeats
-
-    _max_per: Optional[int] = None
 
 
 def grouped_match_loss(gw_syn: List[torch.Tensor], gw_real: List[torch.Tensor], dis_metric: str, G: int, need_grad, pyt: bool = False):
@@ -250,9 +259,6 @@ class FusedDistiller:
         self.syn_pt_off = (torch.arange(G * ipc + 1, device=dev) * num_points).to(_I32)
         self.syn_batch_col = torch.arange(G * ipc, device=dev, dtype=_F32).repeat_interleave(num_points)[:, None]
         self.last = {}
-        # the real and the synthetic pass are independent until the loss: they run on two streams, so the small synthetic kernels and
-        # both chains of latency-bound map kernels overlap with the large real-batch kernels
-        self.stream_real, self.stream_syn = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
         # eager mode: next step's real batch is sampled on its own stream while this step's kernels run
         self.stream_data, self._prefetched = torch.cuda.Stream(dev), None
         self.use_graph = bool(graph) and G > 0
@@ -315,15 +321,23 @@ class FusedDistiller:
         bound = sum(int(np.sort(counts[self.indices_class[c]])[::-1][:n].sum()) for c, n in zip(self.classes, sizes))
         st.bound = max(256, (bound + 255) // 256 * 256)
         st.sizes, st.B = sizes, int(sum(sizes))
+        # merged batch: the synthetic clouds first (fixed sizes), then the sampled real clouds
+        Bs, Ns, G = self.G * self.ipc, self.G * self.ipc * npts, self.G
+        st.bound_total = Ns + st.bound
         st.ids = torch.zeros(max(st.B, 1), dtype=_I32, device=dev)
-        st.coords = torch.zeros((st.bound, 4), dtype=_F32, device=dev)
-        st.feats = torch.zeros((st.bound, 3), dtype=_F32, device=dev)
-        st.pt_off = torch.zeros(st.B + 1, dtype=_I32, device=dev)
+        st.coords = torch.zeros((st.bound_total, 4), dtype=_F32, device=dev)
+        st.coords[:Ns, 0] = self.syn_batch_col[:, 0]
+        st.feats = torch.zeros((st.bound_total, 3), dtype=_F32, device=dev)
+        st.pt_off = torch.zeros(Bs + st.B + 1, dtype=_I32, device=dev)
+        st.pt_off[:Bs + 1] = self.syn_pt_off
         st.n = torch.zeros(1, dtype=_I32, device=dev)
         st.err = torch.zeros(1, dtype=_I32, device=dev)
-        st.labels = torch.tensor(np.repeat(self.classes, sizes), device=dev, dtype=_I32)
-        st.cloud_group = torch.tensor(np.repeat(np.arange(self.G), sizes), device=dev, dtype=_I32)
-        st.gco = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), device=dev, dtype=_I32)
+        rl = torch.tensor(np.repeat(self.classes, sizes), device=dev, dtype=_I32)
+        rg = torch.tensor(np.repeat(np.arange(G), sizes), device=dev, dtype=_I32)
+        rgco = torch.tensor(np.cumsum(sizes), device=dev, dtype=_I32)
+        st.labels = torch.cat([self.syn_labels, rl])
+        st.cloud_group = torch.cat([self.syn_group, rg + G])
+        st.gco = torch.cat([self.syn_gco, rgco + Bs])
         st.max_per = int(max(sizes))
         st.pin = [torch.empty(max(st.B, 1), dtype=_I32).pin_memory() for _ in range(4)]
         st.pin_ev = [torch.cuda.Event() for _ in range(4)]
@@ -341,47 +355,43 @@ class FusedDistiller:
         st.pin_ev[i].record()
 
     # ------------------------------------------------------------------ the step
-    def _compute(self, rb, static):
-        """Everything after the real batch exists: both passes, matching loss, backward into the points, SGD update."""
+    def _merge_eager(self, rb, xyz):
+        """Eager mode: the merged batch (synthetic clouds, then the real batch ``rb``) from host-sized tensors."""
+        G, Bs, Ns = self.G, self.G * self.ipc, xyz.shape[0]
+        rc = rb["coordinates"].clone()
+        rc[:, 0] += Bs
+        pt = rb.get("pt_off")
+        if pt is None:
+            cnt = torch.bincount(rb["coordinates"][:, 0].long(), minlength=int(rb["num_clouds"]))
+            pt = torch.cat([cnt.new_zeros(1), torch.cumsum(cnt, 0)]).to(_I32)
+        return {"coordinates": torch.cat([torch.cat([self.syn_batch_col, xyz], 1), rc]), "features": torch.cat([xyz, rb["features"]]),
+                "labels": torch.cat([self.syn_labels, rb["labels"].to(_I32)]), "num_clouds": Bs + int(rb["num_clouds"]),
+                "cloud_group": torch.cat([self.syn_group, rb["cloud_group"] + G]),
+                "group_cloud_off": torch.cat([self.syn_gco, rb["group_cloud_off"][1:] + Bs]),
+                "pt_off": torch.cat([self.syn_pt_off, pt[1:] + Ns]), "n_dev": None}
+
+    def _compute(self, mb, static):
+        """Everything after the merged batch ``mb`` exists: one forward / first-order backward over synthetic + real clouds, the matching
+        loss, the second-order backward into the synthetic points, the SGD update."""
         dev, G, ipc, npts = self.device, self.G, self.ipc, self.num_points
-        main = torch.cuda.current_stream(dev)
-        B_r = int(rb["num_clouds"])
-        xyz = self.image_syn[self.syn_rows].reshape(-1, 3)           # [G*ipc*npts, 3]; coordinates and features are the same tensor
-        coords = torch.cat([self.syn_batch_col, xyz], 1)
-        # cached layouts of the frozen weights are (re)built here, on the main stream, before the two passes fork
+        # cached layouts of the frozen weights are (re)built here if a weight changed
         from .ops import site_major
         net = self.network
         site_major(net.classifier.weight, 128, net.dense_extent[0] * net.dense_extent[1] * net.dense_extent[2])
         transposed_kernel(net.features[4].kernel)
-        sr, ss = self.stream_real, self.stream_syn
-        if os.environ.get("DD3D_SINGLE_STREAM"):    # experiment switch: both passes on the main stream
-            sr = ss = main
-        sr.wait_stream(main)
-        ss.wait_stream(main)
-        if not static:
-            for t in rb.values():
-                if torch.is_tensor(t):
-                    t.record_stream(sr)
-        with torch.cuda.stream(sr):
-            real = _Pass(self.network, rb["coordinates"], B_r, G, rb["cloud_group"], rb["group_cloud_off"], rb.get("n_dev"), static,
-                         rb.get("pt_off"), npts)
-        with torch.cuda.stream(ss):
-            syn = _Pass(self.network, coords, G * ipc, G, self.syn_group, self.syn_gco, None, static, self.syn_pt_off, npts)
-        with torch.cuda.stream(sr):
-            real.run(rb["features"], rb["labels"], False)
-        with torch.cuda.stream(ss):
-            syn.run(xyz, self.syn_labels, True)
-        syn._max_per = ipc
-        main.wait_stream(sr)
-        main.wait_stream(ss)
+        p = _Pass(net, mb["coordinates"], int(mb["num_clouds"]), 2 * G, mb["cloud_group"], mb["group_cloud_off"], G * ipc, G * ipc * npts,
+                  mb.get("n_dev"), static, mb.get("pt_off"), npts)
+        p.run(mb["features"], mb["labels"])
+        gw_syn, gw_real = [t[:G] for t in p.gw], [t[G:] for t in p.gw]
         # only these entries of gw_syn depend on the synthetic points (SURVEY.md section 3.2): IN weights, classifier weight and bias
         need = [False, True, False, False, True, False, True, True]
-        loss_g, d = grouped_match_loss(syn.gw, real.gw, self.dist_opt, G, need)
-        dfeats = syn.backward_to_points(d[1], d[4], d[6], d[7])
+        loss_g, d = grouped_match_loss(gw_syn, gw_real, self.dist_opt, G, need)
+        dfeats = p.backward_to_points(d[1], d[4], d[6], d[7], ipc)
         grad = torch.zeros_like(self.image_syn)
         grad[self.syn_rows] = dfeats.reshape(G * ipc, npts, 3)
-        self.last = {"per_class": loss_g, "grad": grad, "gw_real": real.gw, "gw_syn": syn.gw, "logits": (real.logits, syn.logits),
-                     "conv1_maps": [(real.maps[4], real.M[1], real.cnt[1]), (syn.maps[4], syn.M[1], syn.cnt[1])], "passes": (real, syn)}
+        Bs = G * ipc
+        self.last = {"per_class": loss_g, "grad": grad, "gw_real": gw_real, "gw_syn": gw_syn, "logits": (p.logits[Bs:], p.logits[:Bs]),
+                     "conv1_maps": [(p.maps[4], p.M[1], p.cnt[1])], "passes": (p,)}
         if self._apply_update:
             # momentum_buf starts at zero, so the first step needs no special case (0.5 * 0 + g == g exactly)
             L.call("dd3d_sgd_momentum_clamp", L.ptr(self.image_syn), L.ptr(grad), L.ptr(self.momentum_buf), self.image_syn.numel(), self.lr,
@@ -392,23 +402,25 @@ class FusedDistiller:
         """clamp + on-device batch assembly + the step, all on fixed addresses with device-side sizes (what the graph captures)."""
         st = self._static
         self.clamp()
-        L.call("dd3d_gather_clouds", L.ptr(st.pool_xyz), L.ptr(st.pool_off), st.n_pool, L.ptr(st.ids), st.B, self.num_points, st.bound,
-               L.ptr(st.coords), L.ptr(st.feats), L.ptr(st.pt_off), L.ptr(st.n), L.ptr(st.err), L.stream())
-        rb = {"coordinates": st.coords, "features": st.feats, "labels": st.labels, "num_clouds": st.B, "cloud_group": st.cloud_group,
+        Bs, Ns = self.G * self.ipc, self.G * self.ipc * self.num_points
+        xyz = self.image_syn[self.syn_rows].reshape(-1, 3)           # coordinates and features of a synthetic point are the same tensor
+        st.coords[:Ns, 1:] = xyz
+        st.feats[:Ns] = xyz
+        L.call("dd3d_gather_clouds", L.ptr(st.pool_xyz), L.ptr(st.pool_off), st.n_pool, L.ptr(st.ids), st.B, self.num_points, st.bound_total,
+               Bs, Ns, L.ptr(st.coords), L.ptr(st.feats), L.ptr(st.pt_off), L.ptr(st.n), L.ptr(st.err), L.stream())
+        mb = {"coordinates": st.coords, "features": st.feats, "labels": st.labels, "num_clouds": Bs + st.B, "cloud_group": st.cloud_group,
               "group_cloud_off": st.gco, "n_dev": st.n, "pt_off": st.pt_off}
         with L.ws_scope(self._scope):
-            return self._compute(rb, True)
+            return self._compute(mb, True)
 
     def row_counts(self):
-        """((M0,M1,M2) real, (M0,M1,M2) synthetic) of the last step (one device->host read in graph mode)."""
-        real, syn = self.last["passes"]
-        return tuple(tuple(int(x) for x in p.cm.counts[:3].tolist()) for p in (real, syn))
+        """((M0, M1, M2),) of the last step's merged batch (one device->host read in graph mode)."""
+        return tuple(tuple(int(x) for x in p.cm.counts[:3].tolist()) for p in self.last["passes"])
 
     def check(self):
         """Raise if any kernel of the last step flagged an error (graph mode defers these checks; eager mode raises in the step)."""
-        real, syn = self.last["passes"]
-        real.cm.check()
-        syn.cm.check()
+        for p in self.last["passes"]:
+            p.cm.check()
         if self._static is not None and int(self._static.err.item()) & 4:
             raise RuntimeError("real-batch assembly: sample index outside the pool, or the batch exceeds its point bound")
 
@@ -444,9 +456,8 @@ class FusedDistiller:
             main.wait_stream(self.stream_data)
         else:
             rb = self.sample_real()
-        rb = dict(rb)
-        rb["labels"] = rb["labels"].to(_I32)
-        total = self._compute(rb, False)
+        xyz = self.image_syn[self.syn_rows].reshape(-1, 3)
+        total = self._compute(self._merge_eager(rb, xyz), False)
         if apply_update:
             self.steps_done += 1
         if real_batch is None and not self.use_graph:

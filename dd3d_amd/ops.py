@@ -262,16 +262,21 @@ class DensePlacement:
         cm._synced = False
 
 
-def sl_fwd_call(F, dp, cloud_group, Wl, strides, J, bias, out):
-    """dd3d_sparse_linear_fwd on raw buffers: out[B,J] = sum over each cloud's voxels of F[v] . Wl[group][.,.,site(v)] (+ bias)."""
-    ws = L.workspace(int(L.lib.dd3d_sparse_linear_ws_bytes(dp.M_bound, J)), F.device)
-    L.call("dd3d_sparse_linear_fwd", L.ptr(F), L.ptr(dp.site), L.ptr(dp.C), dp.M_bound, L.ptr(dp.seg_off), dp.B, 128, L.ptr(cloud_group), L.ptr(Wl),
+def sl_fwd_call(F, dp, cloud_group, Wl, strides, J, bias, out, B=None, M_bound=None):
+    """dd3d_sparse_linear_fwd on raw buffers: out[B,J] = sum over each cloud's voxels of F[v] . Wl[group][.,.,site(v)] (+ bias).
+    ``B`` / ``M_bound``: restrict the call to the first B clouds (their rows are a prefix of the row range, bounded by M_bound)."""
+    B = dp.B if B is None else B
+    M_bound = dp.M_bound if M_bound is None else M_bound
+    ws = L.workspace(int(L.lib.dd3d_sparse_linear_ws_bytes(M_bound, J)), F.device)
+    L.call("dd3d_sparse_linear_fwd", L.ptr(F), L.ptr(dp.site), L.ptr(dp.C), M_bound, L.ptr(dp.seg_off), B, 128, L.ptr(cloud_group), L.ptr(Wl),
            strides, J, L.ptr(bias), L.ptr(out), L.ptr(ws), ws.numel(), L.stream())
 
 
-def sl_bwd_x_call(dl, dp, cloud_group, Wl, strides, J, accumulate, dF):
-    """dd3d_sparse_linear_bwd_x on raw buffers: dF[v] (+)= sum_j dl[cloud(v)][j] * Wl[group][j][., site(v)]."""
-    L.call("dd3d_sparse_linear_bwd_x", L.ptr(dl), L.ptr(dp.site), L.ptr(dp.C), dp.M_bound, L.ptr(dp.seg_off), dp.B, 128, L.ptr(cloud_group), L.ptr(Wl),
+def sl_bwd_x_call(dl, dp, cloud_group, Wl, strides, J, accumulate, dF, B=None, M_bound=None):
+    """dd3d_sparse_linear_bwd_x on raw buffers: dF[v] (+)= sum_j dl[cloud(v)][j] * Wl[group][j][., site(v)] (same B / M_bound)."""
+    B = dp.B if B is None else B
+    M_bound = dp.M_bound if M_bound is None else M_bound
+    L.call("dd3d_sparse_linear_bwd_x", L.ptr(dl), L.ptr(dp.site), L.ptr(dp.C), M_bound, L.ptr(dp.seg_off), B, 128, L.ptr(cloud_group), L.ptr(Wl),
            strides, J, int(accumulate), L.ptr(dF), L.stream())
 
 

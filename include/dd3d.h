@@ -76,12 +76,14 @@ int dd3d_dense_sites(const int32_t* C, const int32_t* m_dev, int64_t bound, cons
                      int E0, int E1, int E2, int32_t* gmin, int32_t* site, int32_t* vox_at, int32_t* err_dev, void* stream);
 
 /* Collated real batch straight from a point pool resident in HBM: cloud b = pool cloud ids[b] (its first `cap` points, pool
- * order), rows (b, p) into coords[bound,4] and p into feats[bound,3]; pt_off[B+1]; *n_dev = rows written.  *err_dev |= 4 if an id
- * is outside [0,n_pool) or the rows do not fit into `bound`.  pool_xyz[.,3] / pool_off[n_pool+1] are built once per dataset.
+ * order), rows (cloud_base + b, p) into coords[bound,4] and p into feats[bound,3] starting at row point_base, so a batch can be
+ * appended behind clouds already in the buffers; pt_off = offsets of the WHOLE batch, entries [cloud_base, cloud_base+B] are
+ * written; *n_dev = point_base + rows written.  *err_dev |= 4 if an id is outside [0,n_pool) or the rows do not fit into `bound`.
+ * pool_xyz[.,3] / pool_off[n_pool+1] are built once per dataset.
  * replaces: get_images -> Mnist2Dreal.__getitem__ (argwhere(image==1)[:num_points]) -> minkowski_collate_fn / sparse_collate,
  * mnist_distill.py:200-208, utils/Mnist2D.py:50-59, utils/MinkowskiCollate.py:4-15 */
-int dd3d_gather_clouds(const float* pool_xyz, const int32_t* pool_off, int n_pool, const int32_t* ids, int B, int cap, int64_t bound, float* coords,
-                       float* feats, int32_t* pt_off, int32_t* n_dev, int32_t* err_dev, void* stream);
+int dd3d_gather_clouds(const float* pool_xyz, const int32_t* pool_off, int n_pool, const int32_t* ids, int B, int cap, int64_t bound, int cloud_base,
+                       int64_t point_base, float* coords, float* feats, int32_t* pt_off, int32_t* n_dev, int32_t* err_dev, void* stream);
 
 /* The whole coordinate pyramid of MEConvExp.forward in three launches, for batches whose clouds have at most
  * dd3d_cloud_maps_max_points() points each: one workgroup per cloud builds the voxel hashes of tensor strides 1, 2, 4 in LDS
@@ -165,7 +167,7 @@ int dd3d_affine_relu_pool_bwd(const float* g_pool, const int32_t* arg, const int
 int64_t dd3d_arp_inorm_bwd_ws_bytes(int B);
 int dd3d_arp_inorm_bwd(const float* g_pool, const int32_t* arg, const int32_t* parent, const float* xhat, const float* inv_std, const float* w,
                        const float* b, int C, const int32_t* seg_off, int B, const int32_t* cloud_group, const int32_t* group_cloud_off, int G,
-                       float* dY, float* ga_out, const float* ga_prev, const float* gw_extra, float* gw_w, float* gw_b, void* ws, int64_t ws_bytes,
+                       float* dY, float* ga_out, int ga_clouds /* ga_out is written for clouds < ga_clouds only; <= 0: all */, const float* ga_prev, const float* gw_extra, float* gw_w, float* gw_b, void* ws, int64_t ws_bytes,
                        void* stream);
 int dd3d_scale_rows_by_group(const float* ga, const float* gw, const int32_t* group_row_off, int G, int64_t M, int C, float* out, void* stream);
 

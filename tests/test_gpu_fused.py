@@ -123,19 +123,31 @@ def test_gather_clouds_equals_collate():
         pt_off = torch.zeros(7, dtype=torch.int32, device=DEV)
         n = torch.zeros(1, dtype=torch.int32, device=DEV)
         err = torch.zeros(1, dtype=torch.int32, device=DEV)
-        L.call("dd3d_gather_clouds", L.ptr(xyz), L.ptr(off), 40, L.ptr(ids), 6, cap, bound, L.ptr(coords), L.ptr(feats), L.ptr(pt_off), L.ptr(n),
+        L.call("dd3d_gather_clouds", L.ptr(xyz), L.ptr(off), 40, L.ptr(ids), 6, cap, bound, 0, 0, L.ptr(coords), L.ptr(feats), L.ptr(pt_off), L.ptr(n),
                L.ptr(err), L.stream())
         N = int(n.item())
         assert N == want["coordinates"].shape[0] and int(err.item()) == 0
         assert torch.equal(coords[:N], want["coordinates"]) and torch.equal(feats[:N], want["features"])
+        assert torch.equal(pt_off, want["pt_off"])
         assert float(coords[N:].max()) == -1.0  # nothing written beyond the count
+        # appended behind 3 clouds / 11 points that are already in the buffers: batch indices and offsets shift, the head is untouched
+        c2, f2 = torch.full((bound, 4), -1.0, device=DEV), torch.full((bound, 3), -1.0, device=DEV)
+        po2 = torch.full((10,), -7, dtype=torch.int32, device=DEV)
+        L.call("dd3d_gather_clouds", L.ptr(xyz), L.ptr(off), 40, L.ptr(ids), 6, cap, bound, 3, 11, L.ptr(c2), L.ptr(f2), L.ptr(po2), L.ptr(n),
+               L.ptr(err), L.stream())
+        assert int(n.item()) == N + 11 and int(err.item()) == 0
+        shifted = want["coordinates"].clone()
+        shifted[:, 0] += 3
+        assert torch.equal(c2[11:N + 11], shifted) and torch.equal(f2[11:N + 11], want["features"])
+        assert float(c2[:11].max()) == -1.0 and float(c2[N + 11:].max()) == -1.0
+        assert torch.equal(po2[3:], want["pt_off"] + 11) and po2[:3].tolist() == [-7, -7, -7]
         # too small a bound, then an id outside the pool: flagged, never out of bounds
-        L.call("dd3d_gather_clouds", L.ptr(xyz), L.ptr(off), 40, L.ptr(ids), 6, cap, 64, L.ptr(coords), L.ptr(feats), L.ptr(pt_off), L.ptr(n),
+        L.call("dd3d_gather_clouds", L.ptr(xyz), L.ptr(off), 40, L.ptr(ids), 6, cap, 64, 0, 0, L.ptr(coords), L.ptr(feats), L.ptr(pt_off), L.ptr(n),
                L.ptr(err), L.stream())
         assert int(err.item()) == 4 and int(n.item()) == 64
         err.zero_()
         bad = torch.tensor([1, 40, -1, 2, 2, 2], dtype=torch.int32, device=DEV)
-        L.call("dd3d_gather_clouds", L.ptr(xyz), L.ptr(off), 40, L.ptr(bad), 6, cap, bound, L.ptr(coords), L.ptr(feats), L.ptr(pt_off), L.ptr(n),
+        L.call("dd3d_gather_clouds", L.ptr(xyz), L.ptr(off), 40, L.ptr(bad), 6, cap, bound, 0, 0, L.ptr(coords), L.ptr(feats), L.ptr(pt_off), L.ptr(n),
                L.ptr(err), L.stream())
         assert int(err.item()) == 4
 

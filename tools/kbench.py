@@ -57,7 +57,7 @@ K = {
  "sl_fwd": (lambda: sl_fwd_call(P1, dp, None, Wsm, sst, J, None, logits), 512 * M2 * (1 + J)),
  "sl_bwd_x": (lambda: sl_bwd_x_call(dl, dp, None, Wsm, sst, J, 0, P1), 512 * M2 * (1 + J)),
  "arp_inorm_bwd L1": (lambda: L.call("dd3d_arp_inorm_bwd", L.ptr(gP0), L.ptr(arg0), L.ptr(cm.parent(2)), L.ptr(xh0), L.ptr(is0), L.ptr(w), L.ptr(bb), 128, L.ptr(seg1), B,
-                                     L.ptr(cg), L.ptr(gco), G, L.ptr(gY0), None, None, None, L.ptr(gw_w), L.ptr(gw_b), L.ptr(ws), ws.numel(), st), 1024 * M0 + 1024 * M1),
+                                     L.ptr(cg), L.ptr(gco), G, L.ptr(gY0), None, 0, None, None, L.ptr(gw_w), L.ptr(gw_b), L.ptr(ws), ws.numel(), st), 1024 * M0 + 1024 * M1),
  "conv128_bww": (lambda: L.call("dd3d_conv_bwd_weight", L.ptr(P0), 128, L.ptr(gY1), 128, L.ptr(k1), ld1, 27, M1, L.ptr(gro2), G, L.ptr(dW1), L.ptr(ws), ws.numel(), st), 0),
  "conv3_bww": (lambda: L.call("dd3d_conv_bwd_weight", L.ptr(F0), 3, L.ptr(gY0), 128, L.ptr(k0), ld0, 27, M0, L.ptr(gro1), G, L.ptr(dW0), L.ptr(ws), ws.numel(), st), 512 * M0 + 120 * M0),
 }
