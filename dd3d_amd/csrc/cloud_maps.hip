@@ -29,6 +29,7 @@ struct CloudSmem {
     int first1[NMAX];                    // stride-1 voxel -> its first point (local index)
     int first2[NMAX], first4[NMAX];      // stride-2 voxel -> its first stride-1 voxel ; stride-4 voxel -> its first stride-2 voxel
     int cnt[NMAX + 1];                   // CSR scratch
+    int box[2][6];                       // bounding boxes of the stride-1 and stride-2 voxels: lo[3], hi[3]
     int s_w[8];
 };
 
@@ -101,14 +102,30 @@ __device__ int lds_unique(const int4* keys, int n, int* tab, int* tmin, int* slo
     return base;
 }
 
+// A key outside the bounding box of the table's voxels cannot be present: no probe.  Flat clouds (MNIST digits: depth 0) lose every
+// offset with a displacement along the flat axis this way -- 18 of the 27 kernel-map offsets, half of the pooling offsets.
 template <int HC>
-__device__ __forceinline__ int lds_lookup(const int* tab, const int4* U, int4 key) {
+__device__ __forceinline__ int lds_lookup(const int* tab, const int4* U, const int* box, int4 key) {
+    if (key.y < box[0] || key.y > box[3] || key.z < box[1] || key.z > box[4] || key.w < box[2] || key.w > box[5]) return -1;
     uint32_t h = hash_coord(key) & (HC - 1);
     for (;;) {
         const int r = tab[h];
         if (r < 0) return -1;
         if (coord_eq(U[r], key)) return r;
         h = (h + 1) & (HC - 1);
+    }
+}
+
+// wave-reduce a thread's partial bounding box, one LDS atomic per wave and bound
+__device__ __forceinline__ void box_merge(int* box, int lo0, int lo1, int lo2, int hi0, int hi1, int hi2) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo0 = min(lo0, __shfl_xor(lo0, o, 64)); lo1 = min(lo1, __shfl_xor(lo1, o, 64)); lo2 = min(lo2, __shfl_xor(lo2, o, 64));
+        hi0 = max(hi0, __shfl_xor(hi0, o, 64)); hi1 = max(hi1, __shfl_xor(hi1, o, 64)); hi2 = max(hi2, __shfl_xor(hi2, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&box[0], lo0); atomicMin(&box[1], lo1); atomicMin(&box[2], lo2);
+        atomicMax(&box[3], hi0); atomicMax(&box[4], hi1); atomicMax(&box[5], hi2);
     }
 }
 
@@ -136,13 +153,32 @@ __device__ CloudCounts build_cloud(CloudSmem<NMAX>& S, const float4* __restrict_
     }
     if (bad) atomicOr(err, 1);
     __syncthreads();
+    if (tid < 12) S.box[tid / 6][tid % 6] = (tid % 6) < 3 ? 0x7FFFFFFF : (int)0x80000000;
     CloudCounts c;
     c.m1 = lds_unique<HC>(S.q, n, S.tab1, S.tmin, S.slot, S.U1, S.lid1, S.first1, S.s_w);
     // stride 2: keys = stride-2 coordinate of every stride-1 voxel (q is free again and serves as key storage)
-    for (int v = tid; v < c.m1; v += CT) S.q[v] = stride_coord(S.U1[v], 2);
+    {
+        int lo0 = 0x7FFFFFFF, lo1 = lo0, lo2 = lo0, hi0 = (int)0x80000000, hi1 = hi0, hi2 = hi0;
+        for (int v = tid; v < c.m1; v += CT) {
+            const int4 u = S.U1[v];
+            S.q[v] = stride_coord(u, 2);
+            lo0 = min(lo0, u.y); lo1 = min(lo1, u.z); lo2 = min(lo2, u.w);
+            hi0 = max(hi0, u.y); hi1 = max(hi1, u.z); hi2 = max(hi2, u.w);
+        }
+        box_merge(S.box[0], lo0, lo1, lo2, hi0, hi1, hi2);
+    }
     __syncthreads();
     c.m2 = lds_unique<HC>(S.q, c.m1, S.tab2, S.tmin, S.slot, S.U2, S.par2, S.first2, S.s_w);
-    for (int v = tid; v < c.m2; v += CT) S.q[v] = stride_coord(S.U2[v], 4);
+    {
+        int lo0 = 0x7FFFFFFF, lo1 = lo0, lo2 = lo0, hi0 = (int)0x80000000, hi1 = hi0, hi2 = hi0;
+        for (int v = tid; v < c.m2; v += CT) {
+            const int4 u = S.U2[v];
+            S.q[v] = stride_coord(u, 4);
+            lo0 = min(lo0, u.y); lo1 = min(lo1, u.z); lo2 = min(lo2, u.w);
+            hi0 = max(hi0, u.y); hi1 = max(hi1, u.z); hi2 = max(hi2, u.w);
+        }
+        box_merge(S.box[1], lo0, lo1, lo2, hi0, hi1, hi2);
+    }
     __syncthreads();
     c.m4 = lds_unique<HC>(S.q, c.m2, S.tab4, S.tmin, S.slot, S.U4, S.par4, S.first4, S.s_w);
     *n_out = n;
@@ -330,7 +366,7 @@ __global__ __launch_bounds__(CT) void k_cloud_emit(const float4* __restrict__ co
         int d0, d1, d2;
         k3_offset(k, 1, &d0, &d1, &d2);
         const int4 u = S.U1[v];
-        const int r = lds_lookup<HC>(S.tab1, S.U1, make_int4(u.x, u.y + d0, u.z + d1, u.w + d2));
+        const int r = lds_lookup<HC>(S.tab1, S.U1, S.box[0], make_int4(u.x, u.y + d0, u.z + d1, u.w + d2));
         o.nbr1[(int64_t)k * o.ld + r1 + v] = r < 0 ? -1 : r1 + r;
     }
     for (int idx = tid; idx < 27 * c.m2; idx += CT) {
@@ -338,20 +374,20 @@ __global__ __launch_bounds__(CT) void k_cloud_emit(const float4* __restrict__ co
         int d0, d1, d2;
         k3_offset(k, 2, &d0, &d1, &d2);
         const int4 u = S.U2[v];
-        const int r = lds_lookup<HC>(S.tab2, S.U2, make_int4(u.x, u.y + d0, u.z + d1, u.w + d2));
+        const int r = lds_lookup<HC>(S.tab2, S.U2, S.box[1], make_int4(u.x, u.y + d0, u.z + d1, u.w + d2));
         o.nbr2[(int64_t)k * o.ld + r2 + v] = r < 0 ? -1 : r2 + r;
     }
     // k=2 pooling maps: children of a stride-2s voxel at offsets {0,1}*s, k = e0 + 2 e1 + 4 e2
     for (int idx = tid; idx < 8 * c.m2; idx += CT) {
         const int k = idx / c.m2, v = idx - k * c.m2;
         const int4 u = S.U2[v];
-        const int r = lds_lookup<HC>(S.tab1, S.U1, make_int4(u.x, u.y + (k & 1), u.z + ((k >> 1) & 1), u.w + (k >> 2)));
+        const int r = lds_lookup<HC>(S.tab1, S.U1, S.box[0], make_int4(u.x, u.y + (k & 1), u.z + ((k >> 1) & 1), u.w + (k >> 2)));
         o.kid2[(int64_t)k * o.ld + r2 + v] = r < 0 ? -1 : r1 + r;
     }
     for (int idx = tid; idx < 8 * c.m4; idx += CT) {
         const int k = idx / c.m4, v = idx - k * c.m4;
         const int4 u = S.U4[v];
-        const int r = lds_lookup<HC>(S.tab2, S.U2, make_int4(u.x, u.y + 2 * (k & 1), u.z + 2 * ((k >> 1) & 1), u.w + 2 * (k >> 2)));
+        const int r = lds_lookup<HC>(S.tab2, S.U2, S.box[1], make_int4(u.x, u.y + 2 * (k & 1), u.z + 2 * ((k >> 1) & 1), u.w + 2 * (k >> 2)));
         o.kid4[(int64_t)k * o.ld + r4 + v] = r < 0 ? -1 : r2 + r;
     }
     // dense() placement of the stride-4 voxels: site = flat index relative to the group's minimum corner
