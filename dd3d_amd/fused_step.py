@@ -45,7 +45,7 @@ class _Pass:
     synthetic clouds come first, their points, voxel rows (at every stride) and clouds are PREFIXES of the arrays: the second-order
     pass is the same kernels called on the first ``B_syn`` clouds with the prefix's row counts (``seg_off[B_syn]``, on the device)."""
 
-    def __init__(self, net, coords, B, G, cloud_group, group_cloud_off, B_syn, N_syn, n_dev=None, static=False, pt_off=None, max_points=0):
+    def __init__(self, net, coords, B, G, cloud_group, group_cloud_off, B_syn, N_syn, side, n_dev=None, static=False, pt_off=None, max_points=0):
         """Phase 1 (no host sync): every coordinate map, enqueued on the current stream.
         ``static``: never read a size back -- every launch covers its bound and takes the true row count from the device
         (``n_dev`` = number of valid rows of ``coords``), so the pass can be captured into a HIP graph."""
@@ -53,7 +53,7 @@ class _Pass:
         self.dev, self.B, self.G, self.net = dev, B, G, net
         self.B_syn, self.N_syn, self.Gs = B_syn, N_syn, G // 2
         self.cloud_group, self.gco = cloud_group, group_cloud_off
-        self.static = static
+        self.static, self.side = static, side
         if pt_off is not None and 0 < max_points <= int(L.lib.dd3d_cloud_maps_max_points()):
             # clouds small enough for LDS: the whole pyramid (+ dense placement) in three launches
             cm = CloudCoordinateManager(coords, pt_off, B, max_points, net.dense_extent, cloud_group, G, group_cloud_off)
@@ -125,23 +125,34 @@ class _Pass:
                L.ptr(closs), L.ptr(self.ce), st)
 
         # ---------------- first-order backward: one gradient list per group ----------------
-        g_cb = _empty((G, J), dev)
-        L.call("dd3d_group_sum_rows", L.ptr(dl), L.ptr(group_cloud_off), G, J, L.ptr(g_cb), st)
-        g_cw = _empty((G, J, 128 * S), dev)
-        pst = (ctypes.c_int64 * 4)(J * 128 * S, 128 * S, S, 1)
-        L.call("dd3d_sparse_linear_bwd_w", L.ptr(dl), L.ptr(P1), L.ptr(dp.vox_at), S, B, L.ptr(group_cloud_off), G, 128, J, L.ptr(g_cw), pst,
-               g_cw.numel(), st)
+        # The parameter gradients of the classifier and of the 128-channel convolution feed nothing but the matching loss, so they run
+        # on a side stream next to the data-gradient chain (sparse linear -> pool/norm -> convolution bwd-data -> pool/norm).
+        main, side = torch.cuda.current_stream(dev), self.side
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            g_cb = _empty((G, J), dev)
+            L.call("dd3d_group_sum_rows", L.ptr(dl), L.ptr(group_cloud_off), G, J, L.ptr(g_cb), L.stream())
+            g_cw = _empty((G, J, 128 * S), dev)
+            pst = (ctypes.c_int64 * 4)(J * 128 * S, 128 * S, S, 1)
+            L.call("dd3d_sparse_linear_bwd_w", L.ptr(dl), L.ptr(P1), L.ptr(dp.vox_at), S, B, L.ptr(group_cloud_off), G, 128, J, L.ptr(g_cw), pst,
+                   g_cw.numel(), L.stream())
         gP1 = _empty((M2, 128), dev)
         sl_bwd_x_call(dl, dp, None, Wsm, sst, J, 0, gP1)
         # the ReLU-masked pooled gradients (ga) are kept for the synthetic clouds only: the second-order pass needs nothing else
         Ns = max(self.N_syn, 1)
         self.ga1, self.ga0 = _empty((Ns, 128), dev), _empty((Ns, 128), dev)
         gY1, g_w5, g_b5 = self._arp_inorm_bwd(gP1, arg1, cm.parent(4), xh1, is1, w5, b5, seg2, M1, B, G, self.ga1, self.B_syn, True)
-        g_W1 = self._bww(P0, 128, gY1, k1, ld1, M1, gro2)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            g_W1 = self._bww(P0, 128, gY1, k1, ld1, M1, gro2)
         gP0 = _empty((M1, 128), dev)
         L.call("dd3d_conv_bwd_data", L.ptr(gY1), M1, c1, 128, L.ptr(W1t), 128, L.ptr(k1), ld1, 27, L.ptr(gP0), st)
         gY0, g_w1, g_b1 = self._arp_inorm_bwd(gP0, arg0, cm.parent(2), xh0, is0, w1, b1, seg1, M0, B, G, self.ga0, self.B_syn, True)
         g_W0 = self._bww(F0, 3, gY0, k0, ld0, M0, gro1)
+        main.wait_stream(side)
+        if not self.static:
+            for t in (g_cb, g_cw, g_W1):   # allocated on the side stream, consumed on the main one
+                t.record_stream(main)
         # order of network.parameters()
         self.gw = [g_W0, g_w1, g_b1, g_W1, g_w5, g_b5, g_cw, g_cb]
         return self
@@ -259,6 +270,7 @@ class FusedDistiller:
         self.syn_pt_off = (torch.arange(G * ipc + 1, device=dev) * num_points).to(_I32)
         self.syn_batch_col = torch.arange(G * ipc, device=dev, dtype=_F32).repeat_interleave(num_points)[:, None]
         self.last = {}
+        self.stream_side = torch.cuda.Stream(dev)   # parameter-gradient kernels that only the loss consumes
         # eager mode: next step's real batch is sampled on its own stream while this step's kernels run
         self.stream_data, self._prefetched = torch.cuda.Stream(dev), None
         self.use_graph = bool(graph) and G > 0
@@ -380,7 +392,7 @@ class FusedDistiller:
         site_major(net.classifier.weight, 128, net.dense_extent[0] * net.dense_extent[1] * net.dense_extent[2])
         transposed_kernel(net.features[4].kernel)
         p = _Pass(net, mb["coordinates"], int(mb["num_clouds"]), 2 * G, mb["cloud_group"], mb["group_cloud_off"], G * ipc, G * ipc * npts,
-                  mb.get("n_dev"), static, mb.get("pt_off"), npts)
+                  self.stream_side, mb.get("n_dev"), static, mb.get("pt_off"), npts)
         p.run(mb["features"], mb["labels"])
         gw_syn, gw_real = [t[:G] for t in p.gw], [t[G:] for t in p.gw]
         # only these entries of gw_syn depend on the synthetic points: IN weights, classifier weight and bias
