@@ -65,14 +65,22 @@ __device__ __forceinline__ f32x4 block_colsum(f32x4 v, f32x4* s_red /*[8*32]*/) 
 // rows in registers, so a cloud of <= RL*CACHE rows is read from HBM exactly once (mean, variance and the normalised write all
 // work on the registers); longer clouds re-read their tail (L2).  Sums run over a thread's rows in ascending order, then over the
 // row-lanes in lane order: deterministic.
+// Column sum over the RL row-lanes of the workgroup (thread = row-lane * CL + channel-lane).  The 64 / CL row-lanes that share a wave
+// are folded with shuffles first, so LDS carries one partial per (wave, channel-lane) and every thread reads RL * CL / 64 of them
+// (an all-to-all through LDS made these kernels LDS-bandwidth-bound).  Fixed order: shuffle tree, then waves ascending.
 template <int RL, int CL = 32>
-__device__ __forceinline__ f32x4 cloud_colsum(f32x4 v, f32x4* s_red /*[RL*CL]*/) {
-    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
-    s_red[rl * CL + cl] = v;
+__device__ __forceinline__ f32x4 cloud_colsum(f32x4 v, f32x4* s_red /*[RL*CL/64 * CL]*/) {
+    constexpr int NW = RL * CL / 64;
+    const int cl = threadIdx.x % CL, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = CL; o < 64; o <<= 1)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += __shfl_xor(v[j], o, 64);
+    if (lane < CL) s_red[w * CL + lane] = v;
     __syncthreads();
     f32x4 s = s_red[cl];
-#pragma unroll 4
-    for (int j = 1; j < RL; ++j) s += s_red[j * CL + cl];
+#pragma unroll 2
+    for (int j = 1; j < NW; ++j) s += s_red[j * CL + cl];
     __syncthreads();
     return s;
 }
@@ -134,6 +142,7 @@ __global__ __launch_bounds__(RL * 32) void k_inorm_bwd(const f32x4* __restrict__
     const int n = r1 - r0;
     if (n <= 0) return;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 is = inv_std[(int64_t)b * 32 + c4];
     f32x4 vg[CACHE], vx[CACHE];
     f32x4 s1 = zero, s2 = zero;
 #pragma unroll
@@ -152,7 +161,6 @@ __global__ __launch_bounds__(RL * 32) void k_inorm_bwd(const f32x4* __restrict__
     }
     const f32x4 m1 = cloud_colsum<RL>(s1, s_red) / (float)n;
     const f32x4 m2 = cloud_colsum<RL>(s2, s_red) / (float)n;
-    const f32x4 is = inv_std[(int64_t)b * 32 + c4];
 #pragma unroll
     for (int i = 0; i < CACHE; ++i) {
         int r = r0 + rl + i * RL;
@@ -310,6 +318,7 @@ __global__ __launch_bounds__(RL * CL) void k_arp_inorm_bwd(const f32x4* __restri
         return;
     }
     const f32x4 ww = w[c4], bb = bias[c4];
+    const f32x4 is = inv_std[(int64_t)b * 32 + c4];  // issued with the first loads, not after the reductions (one round trip less)
     f32x4 ex = zero;
     if (gw_extra) ex = gw_extra[(int64_t)(cloud_group ? cloud_group[b] : 0) * 32 + c4];
     // ga (ReLU-masked pooled gradient) and g_xhat of row i
@@ -361,8 +370,7 @@ __global__ __launch_bounds__(RL * CL) void k_arp_inorm_bwd(const f32x4* __restri
             part[((int64_t)b * 2 + 1) * 32 + c4] = tb;
         }
     }
-    const f32x4 is = inv_std[(int64_t)b * 32 + c4];
-#pragma unroll
+    #pragma unroll
     for (int i = 0; i < CACHE; ++i) {
         const int r = r0 + rl + i * RL;
         if (r < r1) dY[(int64_t)r * 32 + c4] = (vg[i] - vx[i] * m2 - m1) * is;
