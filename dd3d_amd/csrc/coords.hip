@@ -368,7 +368,7 @@ __global__ void k_cloud_offsets(const int* __restrict__ pool_off, const int* __r
 
 // one workgroup per sampled cloud: rows (b, p0, p1, p2) into coords and (p0, p1, p2) into feats, in pool order
 __global__ void k_gather_clouds(const float* __restrict__ pool_xyz, const int* __restrict__ pool_off, const int* __restrict__ ids, int n_pool,
-                                const int* __restrict__ pt_off, int B, int cloud_base, float4* __restrict__ coords, float* __restrict__ feats) {
+                                const int* __restrict__ pt_off, int B, int cloud_base, float quant, float4* __restrict__ coords, float* __restrict__ feats) {
     const int b = blockIdx.x;
     const int id = ids[b];
     if (id < 0 || id >= n_pool) return;
@@ -376,7 +376,7 @@ __global__ void k_gather_clouds(const float* __restrict__ pool_xyz, const int* _
     const float* src = pool_xyz + (int64_t)pool_off[id] * 3;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         float x = src[i * 3 + 0], y = src[i * 3 + 1], z = src[i * 3 + 2];
-        coords[dst0 + i] = make_float4((float)(cloud_base + b), x, y, z);
+        coords[dst0 + i] = make_float4((float)(cloud_base + b), x / quant, y / quant, z / quant);  // create_input_batch: coords / quantization_size
         float* f = feats + (int64_t)(dst0 + i) * 3;
         f[0] = x; f[1] = y; f[2] = z;
     }
@@ -561,18 +561,19 @@ DD3D_API int dd3d_dense_sites(const int32_t* C, const int32_t* m_dev, int64_t bo
 // Collated real batch from a resident point pool: cloud b of the batch = pool cloud ids[b], first `cap` points.  The batch may be
 // appended to clouds that are already in the buffers: its clouds get batch indices cloud_base + b, its points start at row
 // point_base, and pt_off (the array of the WHOLE batch) receives entries [cloud_base, cloud_base + B].  coords[bound,4] /
-// feats[bound,3] (first *n_dev rows valid).  *err_dev |= 4 if an id is outside the pool or the points do not fit into `bound`.
+// feats[bound,3] (first *n_dev rows valid); coordinates are the points divided by `quant` (models/MEConv.py:262), features the raw
+// points.  *err_dev |= 4 if an id is outside the pool or the points do not fit into `bound`.
 DD3D_API int dd3d_gather_clouds(const float* pool_xyz, const int32_t* pool_off, int n_pool, const int32_t* ids, int B, int cap, int64_t bound,
-                                int cloud_base, int64_t point_base, float* coords, float* feats, int32_t* pt_off, int32_t* n_dev, int32_t* err_dev,
-                                void* stream) {
-    if (B < 0 || n_pool < 0 || cap < 0 || bound < 0 || bound >= (1ll << 31) || cloud_base < 0 || point_base < 0 || point_base > bound || !pt_off ||
+                                int cloud_base, int64_t point_base, float quant, float* coords, float* feats, int32_t* pt_off, int32_t* n_dev,
+                                int32_t* err_dev, void* stream) {
+    if (B < 0 || n_pool < 0 || cap < 0 || bound < 0 || bound >= (1ll << 31) || cloud_base < 0 || point_base < 0 || point_base > bound || !(quant > 0.f) || !pt_off ||
         !n_dev || !err_dev)
         return DD3D_EARG;
     if (B > 0 && (!pool_xyz || !pool_off || !ids || !coords || !feats)) return DD3D_EARG;
     hipStream_t st = (hipStream_t)stream;
     int32_t* po = pt_off + cloud_base;
     k_cloud_offsets<<<1, 1024, 0, st>>>(pool_off, ids, B, n_pool, cap, bound, (int)point_base, po, n_dev, err_dev);
-    if (B > 0) k_gather_clouds<<<dim3(B), 128, 0, st>>>(pool_xyz, pool_off, ids, n_pool, po, B, cloud_base, (float4*)coords, feats);
+    if (B > 0) k_gather_clouds<<<dim3(B), 128, 0, st>>>(pool_xyz, pool_off, ids, n_pool, po, B, cloud_base, quant, (float4*)coords, feats);
     DD3D_CHECK_LAUNCH();
     return 0;
 }

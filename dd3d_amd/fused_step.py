@@ -246,9 +246,20 @@ class FusedDistiller:
     Both modes produce bit-identical results (``tests/test_gpu_fused.py``)."""
 
     def __init__(self, images_all, indices_class, network, ipc, num_classes=10, num_points=250, batch_size=256, dist_opt="modmse",
-                 dist_lr=0.1, device=None, seed=0, image_syn=None, classes=None, momentum=0.5, graph=True):
+                 dist_lr=0.1, device=None, seed=0, image_syn=None, classes=None, momentum=0.5, graph=True, real_clouds=None,
+                 quantization_size=1.0, clamp_range=(0.0, 27.0), zero_first_axis=True):
+        """``real_clouds`` (optional, instead of ``images_all``): the real data as point clouds -- a float tensor [n, P, 3] or a list of
+        [n_i, 3] tensors; coordinates = features = the points (what Mnist2Dreal does with pixels), coordinates divided by
+        ``quantization_size`` (create_input_batch).  ``clamp_range`` / ``zero_first_axis``: the per-iteration clamp of the synthetic
+        points (mnist_distill.py:311-317: [0, 27], depth := 0); ``clamp_range=None`` switches it off for 3-D clouds."""
         self.device = dev = torch.device(device or "cuda")
-        self.images_all = images_all.to(dev)
+        self.images_all = images_all.to(dev) if images_all is not None else None
+        self.quant, self.clamp_range, self.zero_first_axis = float(quantization_size), clamp_range, bool(zero_first_axis)
+        self._pool = None
+        if real_clouds is not None:   # point pool straight from the clouds (first num_points points of each)
+            cl = [c[:num_points] for c in real_clouds]
+            cnt = torch.tensor([0] + [int(c.shape[0]) for c in cl])
+            self._pool = (torch.cat([c.reshape(-1, 3) for c in cl]).to(dev, _F32).contiguous(), torch.cumsum(cnt, 0).to(dev, _I32))
         self.indices_class = [np.asarray(ix) for ix in indices_class]
         self.network = network.to(dev).train()
         self.num_classes, self.ipc, self.num_points, self.batch_size = num_classes, ipc, num_points, batch_size
@@ -285,8 +296,26 @@ class FusedDistiller:
 
     def clamp(self):
         s = self.image_syn
-        s.clamp_(0, 27)
-        s[:, :, 0] = 0
+        if self.clamp_range is not None:
+            s.clamp_(self.clamp_range[0], self.clamp_range[1])
+        if self.zero_first_axis:
+            s[:, :, 0] = 0
+
+    def _point_pool(self):
+        """(pool_xyz [total,3], pool_off [n+1]): every real cloud's points (its first num_points), resident in HBM, built once."""
+        if self._pool is None:
+            dev, npts = self.device, self.num_points
+            n_img = int(self.images_all.shape[0])
+            off, xyz, total = [torch.zeros(1, dtype=torch.int64, device=dev)], [], 0
+            for a in range(0, n_img, 8192):           # chunks keep the one-time nonzero() temporaries small
+                imgs = self.images_all[a:a + 8192]
+                b = batch_from_images(imgs, torch.zeros(imgs.shape[0], dtype=torch.int64, device=dev), npts)
+                cnt = torch.bincount(b["coordinates"][:, 0].long(), minlength=imgs.shape[0])
+                off.append(torch.cumsum(cnt, 0) + total)
+                total += int(cnt.sum().item())
+                xyz.append(b["features"])
+            self._pool = (torch.cat(xyz).contiguous() if total else torch.zeros((1, 3), device=dev), torch.cat(off).to(_I32).contiguous())
+        return self._pool
 
     # ------------------------------------------------------------------ eager-mode real batch (host-sized tensors)
     def _draw(self):
@@ -297,12 +326,31 @@ class FusedDistiller:
         """mnist_distill.py:200-208 for every owned class at once: one gather + one nonzero."""
         idx = self._draw()
         sizes = [min(self.batch_size, len(self.indices_class[c])) for c in self.classes]
+        if self.images_all is None:
+            return self.real_batch_from_pool(idx, sizes)
         return self.real_batch_from_images(self.images_all[torch.as_tensor(idx, device=self.device)], sizes)
+
+    def real_batch_from_pool(self, idx, sizes):
+        """The collated batch of the sampled clouds ``idx`` (coordinates = points / quantization_size, features = points)."""
+        dev = self.device
+        xyz, off = self._point_pool()
+        ids = torch.as_tensor(np.asarray(idx), device=dev).long()
+        start, cnt = off[ids].long(), (off[ids + 1] - off[ids]).long()
+        pt = torch.cat([cnt.new_zeros(1), torch.cumsum(cnt, 0)])
+        b = torch.repeat_interleave(torch.arange(ids.numel(), device=dev), cnt)
+        rows = start[b] + (torch.arange(int(pt[-1]), device=dev) - pt[b])
+        p = xyz[rows]
+        return {"coordinates": torch.cat([b[:, None].to(_F32), p / self.quant], 1), "features": p.clone(), "num_clouds": int(ids.numel()),
+                "labels": torch.tensor(np.repeat(self.classes, sizes), device=dev), "pt_off": pt.to(_I32),
+                "cloud_group": torch.tensor(np.repeat(np.arange(self.G), sizes), device=dev, dtype=_I32),
+                "group_cloud_off": torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), device=dev, dtype=_I32), "max_per": int(max(sizes))}
 
     def real_batch_from_images(self, images, sizes):
         dev = self.device
         labels = torch.tensor(np.repeat(self.classes, sizes), device=dev)
         b = batch_from_images(images, labels, self.num_points)
+        if self.quant != 1.0:
+            b["coordinates"][:, 1:] /= self.quant
         b["cloud_group"] = torch.tensor(np.repeat(np.arange(self.G), sizes), device=dev, dtype=_I32)
         b["group_cloud_off"] = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), device=dev, dtype=_I32)
         b["max_per"] = int(max(sizes))
@@ -312,21 +360,9 @@ class FusedDistiller:
     def _build_static(self):
         """Point pool of the whole image set (CSR, resident in HBM) and the fixed-address buffers of the captured step."""
         dev, npts = self.device, self.num_points
-        n_img = int(self.images_all.shape[0])
-        off = [torch.zeros(1, dtype=torch.int64, device=dev)]
-        xyz = []
-        total = 0
-        for a in range(0, n_img, 8192):           # chunks keep the one-time nonzero() temporaries small
-            imgs = self.images_all[a:a + 8192]
-            b = batch_from_images(imgs, torch.zeros(imgs.shape[0], dtype=torch.int64, device=dev), npts)
-            cnt = torch.bincount(b["coordinates"][:, 0].long(), minlength=imgs.shape[0])
-            off.append(torch.cumsum(cnt, 0) + total)
-            total += int(cnt.sum().item())
-            xyz.append(b["features"])
         st = type("Static", (), {})()
-        st.pool_off = torch.cat(off).to(_I32).contiguous()
-        st.pool_xyz = torch.cat(xyz).contiguous() if total else torch.zeros((1, 3), device=dev)
-        st.n_pool = n_img
+        st.pool_xyz, st.pool_off = self._point_pool()
+        st.n_pool = int(st.pool_off.numel()) - 1
         counts = (st.pool_off[1:] - st.pool_off[:-1]).cpu().numpy()
         sizes = [min(self.batch_size, len(self.indices_class[c])) for c in self.classes]
         # tight bound on the points of one sampled batch: the `size` largest clouds of every class
@@ -376,7 +412,7 @@ class FusedDistiller:
         if pt is None:
             cnt = torch.bincount(rb["coordinates"][:, 0].long(), minlength=int(rb["num_clouds"]))
             pt = torch.cat([cnt.new_zeros(1), torch.cumsum(cnt, 0)]).to(_I32)
-        return {"coordinates": torch.cat([torch.cat([self.syn_batch_col, xyz], 1), rc]), "features": torch.cat([xyz, rb["features"]]),
+        return {"coordinates": torch.cat([torch.cat([self.syn_batch_col, xyz / self.quant], 1), rc]), "features": torch.cat([xyz, rb["features"]]),
                 "labels": torch.cat([self.syn_labels, rb["labels"].to(_I32)]), "num_clouds": Bs + int(rb["num_clouds"]),
                 "cloud_group": torch.cat([self.syn_group, rb["cloud_group"] + G]),
                 "group_cloud_off": torch.cat([self.syn_gco, rb["group_cloud_off"][1:] + Bs]),
@@ -416,10 +452,10 @@ class FusedDistiller:
         self.clamp()
         Bs, Ns = self.G * self.ipc, self.G * self.ipc * self.num_points
         xyz = self.image_syn[self.syn_rows].reshape(-1, 3)           # coordinates and features of a synthetic point are the same tensor
-        st.coords[:Ns, 1:] = xyz
+        st.coords[:Ns, 1:] = xyz / self.quant if self.quant != 1.0 else xyz   # create_input_batch: coordinates / quantization_size
         st.feats[:Ns] = xyz
         L.call("dd3d_gather_clouds", L.ptr(st.pool_xyz), L.ptr(st.pool_off), st.n_pool, L.ptr(st.ids), st.B, self.num_points, st.bound_total,
-               Bs, Ns, L.ptr(st.coords), L.ptr(st.feats), L.ptr(st.pt_off), L.ptr(st.n), L.ptr(st.err), L.stream())
+               Bs, Ns, self.quant, L.ptr(st.coords), L.ptr(st.feats), L.ptr(st.pt_off), L.ptr(st.n), L.ptr(st.err), L.stream())
         mb = {"coordinates": st.coords, "features": st.feats, "labels": st.labels, "num_clouds": Bs + st.B, "cloud_group": st.cloud_group,
               "group_cloud_off": st.gco, "n_dev": st.n, "pt_off": st.pt_off}
         with L.ws_scope(self._scope):

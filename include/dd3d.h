@@ -83,7 +83,7 @@ int dd3d_dense_sites(const int32_t* C, const int32_t* m_dev, int64_t bound, cons
  * replaces: get_images -> Mnist2Dreal.__getitem__ (argwhere(image==1)[:num_points]) -> minkowski_collate_fn / sparse_collate,
  * mnist_distill.py:200-208, utils/Mnist2D.py:50-59, utils/MinkowskiCollate.py:4-15 */
 int dd3d_gather_clouds(const float* pool_xyz, const int32_t* pool_off, int n_pool, const int32_t* ids, int B, int cap, int64_t bound, int cloud_base,
-                       int64_t point_base, float* coords, float* feats, int32_t* pt_off, int32_t* n_dev, int32_t* err_dev, void* stream);
+                       int64_t point_base, float quant /* coords = p / quant (create_input_batch's quantization_size), feats = p */, float* coords, float* feats, int32_t* pt_off, int32_t* n_dev, int32_t* err_dev, void* stream);
 
 /* The whole coordinate pyramid of MEConvExp.forward in three launches, for batches whose clouds have at most
  * dd3d_cloud_maps_max_points() points each: one workgroup per cloud builds the voxel hashes of tensor strides 1, 2, 4 in LDS

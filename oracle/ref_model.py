@@ -51,9 +51,13 @@ def create_input_batch(batch, is_minknet=True, device="cpu", quantization_size=0
 class MEConvExp(ME.MinkowskiNetwork):
     """models/MEConv.py:208-258: (Conv k3 -> InstanceNorm(128) -> ReLU -> MaxPool k2 s2) x2, dense, Linear(100352,10)."""
 
-    def __init__(self, in_channel, out_channel, embedding_channel=1024, dimension=3, full_minkowski=False):
+    def __init__(self, in_channel, out_channel, embedding_channel=1024, dimension=3, full_minkowski=False, *, num_classes=10,
+                 dense_extent=(1, 28, 28)):
+        """``num_classes`` / ``dense_extent``: keyword-only openings of the reference's hard-coded MNIST geometry (Linear(100352,10),
+        dense shape [B,128,1,28,28]) for the ModelNet/ShapeNet-shaped configs; the defaults are the reference's values."""
         super().__init__(dimension)
         self.full_minkowski = full_minkowski
+        self.dense_extent = tuple(int(e) for e in dense_extent)
         layers: List[nn.Module] = []
         cin = in_channel
         for _ in range(2):
@@ -65,14 +69,15 @@ class MEConvExp(ME.MinkowskiNetwork):
         for m in self.modules():  # :232-242
             if isinstance(m, ME.MinkowskiConvolution):
                 ME.kaiming_normal_(m.kernel, mode="fan_out", nonlinearity="relu")
-        self.classifier = nn.Linear(100352, 10)
+        self.n_dense = 128 * self.dense_extent[0] * self.dense_extent[1] * self.dense_extent[2]
+        self.classifier = nn.Linear(self.n_dense, num_classes)
 
     def forward(self, x: ME.TensorField):
         out = self.features(x.sparse())
         B = int(torch.max(x.C, dim=0).values[0].item()) + 1  # :250
         min_coord = out.C.min(0, keepdim=True)[0][:, 1:].cpu()  # :251-253, min over the WHOLE batch
-        dense = out.dense(shape=torch.Size([B, 128, 1, 28, 28]), min_coordinate=min_coord)[0]
-        return self.classifier(dense.view(-1, 100352))
+        dense = out.dense(shape=torch.Size([B, 128, *self.dense_extent]), min_coordinate=min_coord)[0]
+        return self.classifier(dense.view(-1, self.n_dense))
 
 
 class MEPytorch(ME.MinkowskiNetwork):
@@ -162,10 +167,11 @@ def clamp_synthetic_(image_syn: torch.Tensor):
 
 
 def matching_step(network, image_syn, real_images_per_class, ipc, dist_opt="modmse", pyt=False,
-                  optimizer=None, num_points=250):
+                  optimizer=None, num_points=250, quantization_size=1):
     """mnist_distill.py:333-369 for one iteration.
 
-    real_images_per_class[c]: {0,1} float tensor [n_c,1,28,28] (the already-sampled real batch of class c).
+    real_images_per_class[c]: {0,1} float tensor [n_c,1,28,28] (the already-sampled real batch of class c), or -- for the
+    point-cloud configs -- a list of [n_i,3] float clouds (coordinates = features = the points, as Mnist2Dreal does with pixels).
     image_syn: leaf tensor [num_classes*ipc, num_points, 3] with requires_grad=True.
     Returns dict(loss, per_class, gw_real, gw_syn (detached), grad) and applies optimizer.step() if given."""
     criterion = nn.CrossEntropyLoss()
@@ -173,11 +179,14 @@ def matching_step(network, image_syn, real_images_per_class, ipc, dist_opt="modm
     loss = torch.tensor(0.0, dtype=image_syn.dtype)
     per_class, gws_all, gwr_all, logits_all = [], [], [], []
     for c, imgs in enumerate(real_images_per_class):
-        labels = torch.full((imgs.shape[0],), c, dtype=torch.long)
-        batch = collate([real_item(imgs[i], labels[i], num_points) for i in range(imgs.shape[0])])
+        labels = torch.full((len(imgs),), c, dtype=torch.long)
+        if torch.is_tensor(imgs):
+            batch = collate([real_item(imgs[i], labels[i], num_points) for i in range(imgs.shape[0])])
+        else:
+            batch = collate([syn_item(imgs[i][:num_points], labels[i]) for i in range(len(imgs))])
         batch["coordinates"] = batch["coordinates"].to(image_syn.dtype)
         batch["features"] = batch["features"].to(image_syn.dtype)
-        out = network(create_input_batch(batch, True, device="cpu", quantization_size=1))
+        out = network(create_input_batch(batch, True, device="cpu", quantization_size=quantization_size))
         loss_real = criterion(out, batch["labels"])
         gw_real = [g.detach().clone() for g in torch.autograd.grad(loss_real, params)]
         syn = image_syn[c * ipc:(c + 1) * ipc]
@@ -186,7 +195,7 @@ def matching_step(network, image_syn, real_images_per_class, ipc, dist_opt="modm
         c_, f_, l_ = ME.sparse_collate([d["coordinates"] for d in items], [d["features"] for d in items],
                                        [d["label"].reshape(1) for d in items], dtype=image_syn.dtype)
         sbatch = {"coordinates": c_, "features": f_, "labels": l_}
-        out_s = network(create_input_batch(sbatch, True, device="cpu", quantization_size=1))
+        out_s = network(create_input_batch(sbatch, True, device="cpu", quantization_size=quantization_size))
         loss_syn = criterion(out_s, sbatch["labels"])
         gw_syn = torch.autograd.grad(loss_syn, params, create_graph=True)
         m = match_loss(gw_syn, gw_real, dist_opt, "cpu", pyt)

@@ -123,7 +123,7 @@ def test_gather_clouds_equals_collate():
         pt_off = torch.zeros(7, dtype=torch.int32, device=DEV)
         n = torch.zeros(1, dtype=torch.int32, device=DEV)
         err = torch.zeros(1, dtype=torch.int32, device=DEV)
-        L.call("dd3d_gather_clouds", L.ptr(xyz), L.ptr(off), 40, L.ptr(ids), 6, cap, bound, 0, 0, L.ptr(coords), L.ptr(feats), L.ptr(pt_off), L.ptr(n),
+        L.call("dd3d_gather_clouds", L.ptr(xyz), L.ptr(off), 40, L.ptr(ids), 6, cap, bound, 0, 0, 1.0, L.ptr(coords), L.ptr(feats), L.ptr(pt_off), L.ptr(n),
                L.ptr(err), L.stream())
         N = int(n.item())
         assert N == want["coordinates"].shape[0] and int(err.item()) == 0
@@ -133,7 +133,7 @@ def test_gather_clouds_equals_collate():
         # appended behind 3 clouds / 11 points that are already in the buffers: batch indices and offsets shift, the head is untouched
         c2, f2 = torch.full((bound, 4), -1.0, device=DEV), torch.full((bound, 3), -1.0, device=DEV)
         po2 = torch.full((10,), -7, dtype=torch.int32, device=DEV)
-        L.call("dd3d_gather_clouds", L.ptr(xyz), L.ptr(off), 40, L.ptr(ids), 6, cap, bound, 3, 11, L.ptr(c2), L.ptr(f2), L.ptr(po2), L.ptr(n),
+        L.call("dd3d_gather_clouds", L.ptr(xyz), L.ptr(off), 40, L.ptr(ids), 6, cap, bound, 3, 11, 1.0, L.ptr(c2), L.ptr(f2), L.ptr(po2), L.ptr(n),
                L.ptr(err), L.stream())
         assert int(n.item()) == N + 11 and int(err.item()) == 0
         shifted = want["coordinates"].clone()
@@ -142,12 +142,12 @@ def test_gather_clouds_equals_collate():
         assert float(c2[:11].max()) == -1.0 and float(c2[N + 11:].max()) == -1.0
         assert torch.equal(po2[3:], want["pt_off"] + 11) and po2[:3].tolist() == [-7, -7, -7]
         # too small a bound, then an id outside the pool: flagged, never out of bounds
-        L.call("dd3d_gather_clouds", L.ptr(xyz), L.ptr(off), 40, L.ptr(ids), 6, cap, 64, 0, 0, L.ptr(coords), L.ptr(feats), L.ptr(pt_off), L.ptr(n),
+        L.call("dd3d_gather_clouds", L.ptr(xyz), L.ptr(off), 40, L.ptr(ids), 6, cap, 64, 0, 0, 1.0, L.ptr(coords), L.ptr(feats), L.ptr(pt_off), L.ptr(n),
                L.ptr(err), L.stream())
         assert int(err.item()) == 4 and int(n.item()) == 64
         err.zero_()
         bad = torch.tensor([1, 40, -1, 2, 2, 2], dtype=torch.int32, device=DEV)
-        L.call("dd3d_gather_clouds", L.ptr(xyz), L.ptr(off), 40, L.ptr(bad), 6, cap, bound, 0, 0, L.ptr(coords), L.ptr(feats), L.ptr(pt_off), L.ptr(n),
+        L.call("dd3d_gather_clouds", L.ptr(xyz), L.ptr(off), 40, L.ptr(bad), 6, cap, bound, 0, 0, 1.0, L.ptr(coords), L.ptr(feats), L.ptr(pt_off), L.ptr(n),
                L.ptr(err), L.stream())
         assert int(err.item()) == 4
 
@@ -172,3 +172,48 @@ def test_graph_replay_is_bitwise_the_eager_step(metric):
         sizes.add(fg.row_counts()[0])
     fg.check()
     assert fg._graph is not None and len(sizes) > 1  # the graph really replayed over batches of different sizes
+
+
+@pytest.mark.parametrize("metric", ["modmse", "ours"])
+def test_fused_3d_point_clouds_vs_oracle(metric):
+    """ModelNet/ShapeNet-shaped case (BASELINE configs 4-5 in small): real data given as 3-D point clouds in [-1,1]^3, voxel size
+    0.05, all 27 kernel offsets active, 300-point clouds (the 1024-point LDS map builder), num_classes / dense_extent keyword
+    extensions -- graph replay and eager step against the CPU oracle: loss and xyz gradient within 1e-4, then graph == eager bitwise."""
+    from dd3d_amd.fused_step import FusedDistiller
+    from dd3d_amd.models.MEConv import MEConvExp
+    from dd3d_amd.synthetic import shell_clouds
+    nclass, per, ipc, npts, q, ext, lr = 3, 6, 2, 300, 0.05, (16, 16, 16), 1e-5
+    clouds = shell_clouds(nclass * per, npts, seed=21)
+    idx = [list(range(c * per, (c + 1) * per)) for c in range(nclass)]
+    g = torch.Generator().manual_seed(4)
+    syn = (torch.rand((nclass * ipc, npts, 3), generator=g) * 1.6 - 0.8).float()
+
+    def net():
+        torch.manual_seed(0)
+        m = MEConvExp(3, nclass, num_classes=nclass, dense_extent=ext)
+        m.load_state_dict(det_state_dict(m, "net.3d"))
+        return m.to(DEV).train()
+
+    kw = dict(ipc=ipc, num_classes=nclass, num_points=npts, batch_size=per, dist_opt=metric, device=DEV, seed=3, image_syn=syn,
+              real_clouds=clouds, quantization_size=q, clamp_range=None, zero_first_axis=False, dist_lr=lr)
+    fe = FusedDistiller(None, idx, net(), graph=False, **kw)
+    fg = FusedDistiller(None, idx, net(), graph=True, **kw)
+    # batch_size == clouds per class, so every step takes all of them (in a seeded order): the oracle sees the same sample
+    rng = np.random.RandomState(3)
+    onet = R.MEConvExp(3, nclass, num_classes=nclass, dense_extent=ext)
+    onet.load_state_dict(det_state_dict(onet, "net.3d"))
+    onet = onet.double().train()
+    osyn = syn.clone().double().requires_grad_()
+    opt = torch.optim.SGD([osyn], lr=lr, momentum=0.5)   # small steps: the unclamped points must stay inside the dense extent
+    for step in range(3):
+        order = [rng.permutation(np.asarray(idx[c]))[:per] for c in range(nclass)]
+        reals = [[clouds[i].double() for i in o] for o in order]
+        ref = R.matching_step(onet, osyn, reals, ipc, metric, False, optimizer=opt, num_points=npts, quantization_size=q)
+        le, lg = fe.outer_step(), fg.outer_step()
+        assert lg.item() == le.item() and torch.equal(fg.image_syn, fe.image_syn), f"step {step}: graph != eager"
+        if step == 0:   # later steps: a synthetic point within rounding of a voxel face may quantise differently in fp32 and fp64
+            assert le.item() == pytest.approx(ref["loss"].item(), rel=1e-4)
+            assert rel_err(fe.last["grad"], ref["grad"]) < 1e-4
+            assert rel_err(fe.image_syn, osyn) < 1e-5
+    fg.check()
+    assert fg._graph is not None and fg.row_counts()[0][0] > 3000
