@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--ipc", type=int, default=IPC)
     ap.add_argument("--metric-name", default="modmse", help="dist_opt: modmse (INI default) | ours | mse | cos")
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4"],
+                    help="BASELINE.json configs: cfg2 (default, the metric's configuration), cfg3 = cfg2 with 50 clouds/class, "
+                         "cfg4 = 40 classes x 256 real ellipsoid-shell clouds x 1024 pts, voxel 0.05, ipc 10 (record runs, not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--emulate-shard", default="", help="R/W: time rank R's share of a W-rank job on this one GPU (no process group)")
     ap.add_argument("--path", default="graph", choices=["graph", "fused", "dropin"],
@@ -84,16 +87,31 @@ def main():
     from dd3d_amd import ops as _ops
 
     torch.manual_seed(0)
-    images_all, _labels, indices_class = mnist3d_like(NUM_CLASSES, POOL_PER_CLASS, seed=0)
-    net = MEConvExp(in_channel=3, out_channel=10)
-    syn = init_synthetic(NUM_CLASSES, args.ipc, NUM_POINTS, seed=0)
     from dd3d_amd.sharding import max_over_ranks, owned_classes, reduce_loss
-    my_classes = owned_classes(NUM_CLASSES, rank, world)
+    n_classes, n_points, extra = NUM_CLASSES, NUM_POINTS, {}
+    if args.config == "cfg3":
+        args.ipc = 50
+    if args.config == "cfg4":
+        from dd3d_amd.synthetic import shell_clouds
+        n_classes, n_points = 40, 1024
+        images_all = None
+        indices_class = [list(range(c * 320, (c + 1) * 320)) for c in range(n_classes)]
+        net = MEConvExp(in_channel=3, out_channel=n_classes, num_classes=n_classes, dense_extent=(12, 12, 12))
+        g = torch.Generator().manual_seed(0)
+        syn = (torch.rand((n_classes * args.ipc, n_points, 3), generator=g) * 1.8 - 0.9).float()
+        extra = dict(real_clouds=shell_clouds(n_classes * 320, n_points, seed=0), quantization_size=0.05, clamp_range=(-0.95, 0.95),
+                     zero_first_axis=False, dist_lr=1e-6)
+        args.no_cpu_baseline = True
+    else:
+        images_all, _labels, indices_class = mnist3d_like(NUM_CLASSES, POOL_PER_CLASS, seed=0)
+        net = MEConvExp(in_channel=3, out_channel=10)
+        syn = init_synthetic(NUM_CLASSES, args.ipc, NUM_POINTS, seed=0)
+    my_classes = owned_classes(n_classes, rank, world)
     if args.emulate_shard:
         er, ew = (int(x) for x in args.emulate_shard.split("/"))
-        my_classes = owned_classes(NUM_CLASSES, er, ew)
-    kw = dict(ipc=args.ipc, num_classes=NUM_CLASSES, num_points=NUM_POINTS, batch_size=REAL_PER_CLASS, dist_opt=args.metric_name, device=dev,
-              seed=1234, image_syn=syn, classes=my_classes)
+        my_classes = owned_classes(n_classes, er, ew)
+    kw = dict(ipc=args.ipc, num_classes=n_classes, num_points=n_points, batch_size=REAL_PER_CLASS, dist_opt=args.metric_name, device=dev,
+              seed=1234, image_syn=syn, classes=my_classes, **extra)
     if args.path == "dropin":
         d = Distiller(images_all, indices_class, net, **kw)
     else:
@@ -163,13 +181,15 @@ def main():
         # HBM bytes per launch of this kernel: PMC counters cannot be read from inside the process, so the figure comes from the
         # committed rocprofv3 --pmc passes of this same command (tools/pmc.sh -> tools/pmc_to_json.py), corrected as the file says
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv128.json")
-        if args.path != "dropin" and args.ipc == IPC and os.path.exists(pmc):
+        if args.path != "dropin" and args.config == "cfg2" and args.ipc == IPC and os.path.exists(pmc):
             roof["traffic"] = json.load(open(pmc))["traffic_bytes_per_launch_avg_real_syn"]
             roof["traffic_source"] = "profiles/r01_pmc_conv128.json"
         out = {"metric": METRIC, "value": args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-               "data": "synthetic", "config": {"workload": f"cfg2: MNIST-3D-shaped stroke digits, {NUM_CLASSES} classes x {REAL_PER_CLASS} real clouds, "
-                                                           f"ipc={args.ipc} x {NUM_POINTS} pts, MEConvExp, dist_opt={args.metric_name}",
+               "data": "synthetic", "config": {"workload": (f"{args.config}: MNIST-3D-shaped stroke digits, {NUM_CLASSES} classes x {REAL_PER_CLASS} real clouds, "
+                                                            f"ipc={args.ipc} x {NUM_POINTS} pts, MEConvExp, dist_opt={args.metric_name}") if args.config != "cfg4" else
+                                                           (f"cfg4: ModelNet40-shaped ellipsoid shells, 40 classes x {REAL_PER_CLASS} real clouds x 1024 pts, voxel 0.05, "
+                                                            f"ipc={args.ipc}, MEConvExp(num_classes=40, dense_extent=12^3), dist_opt={args.metric_name}"),
                                                "parallelism": f"class-sharded x{world}",
                                                "path": {"graph": "class-batched step, one HIP graph replay per step", "fused": "class-batched step, eager launches",
                                                         "dropin": "drop-in autograd loop"}[args.path]},
