@@ -169,6 +169,119 @@ __global__ __launch_bounds__(256) void k_conv128(const float* __restrict__ X, co
             }
 }
 
+// Row-private variant for large launches: wave w of the workgroup owns output rows [32w, 32w+32) of the tile and ALL 128 columns
+// (four independent 32x32 accumulators; lane i32 of column block n holds column 4*i32 + n, so one ds_read_b128 feeds four MFMAs and
+// the epilogue stores float4s).  The gathered A rows are private to the wave and go global -> registers (no LDS, no barrier); only
+// the 16 KB weight chunk of a step is shared, double-buffered in LDS: ONE barrier per step, and the loads of step s+1 (A into the
+// other register set, W into staging registers) are in flight under the 64 MFMAs of step s.  The k-index assignment and the
+// order of the accumulation are those of k_conv128, so the two kernels give bit-identical results.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_conv128_rows(const float* __restrict__ X, const float* __restrict__ W, const int* __restrict__ nbr, int64_t ld,
+                                                          int K, int M_bound, const int* __restrict__ m_dev, int mirror, float* __restrict__ Y, int xcd_remap) {
+    constexpr int TM = NW * 32, NTH = NW * 64, BPT = 1024 / NTH;
+    __shared__ f32x4 Bs4[2][32 * 32];
+    __shared__ int s_nbr[27 * TM];
+    __shared__ unsigned s_kmask;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int i32 = lane & 31, h = lane >> 5;
+    const int M_out = m_dev ? min(*m_dev, M_bound) : M_bound;
+    const int ntile = (M_out + TM - 1) / TM, per_xcd = (ntile + 7) / 8;
+    const int tile = xcd_remap ? (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int64_t row0 = (int64_t)tile * TM;
+    if (tile >= ntile || (xcd_remap && (int)(blockIdx.x >> 3) >= per_xcd)) return;
+
+    if (tid == 0) s_kmask = 0;
+    __syncthreads();
+    unsigned mymask = 0;
+    for (int idx = tid; idx < K * TM; idx += NTH) {
+        int k = idx / TM, r = idx - k * TM;
+        int64_t row = row0 + r;
+        int ks = mirror ? K - 1 - k : k;
+        int v = row < M_out ? nbr[(int64_t)ks * ld + row] : -1;
+        s_nbr[idx] = v;
+        if (v >= 0) mymask |= 1u << k;
+    }
+    if (mymask) atomicOr(&s_kmask, mymask);
+    __syncthreads();
+    const unsigned kmask = s_kmask;
+    unsigned wmask = 0;  // offsets with a neighbour for one of THIS wave's 32 rows
+    for (unsigned rest = kmask; rest; rest &= rest - 1) {
+        const int k = __builtin_ctz(rest);
+        if (__ballot(s_nbr[k * TM + wid * 32 + i32] >= 0)) wmask |= 1u << k;
+    }
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    const f32x4* X4 = (const f32x4*)X;
+    const f32x4* W4 = (const f32x4*)W;
+
+    f32x4 raA[4], raB[4], rb[BPT];
+    auto load_a = [&](f32x4(&ra)[4], int nb, int kc) {  // clamped address: no branch, the four loads are issued together
+        const f32x4* p = X4 + (int64_t)max(nb, 0) * 32 + kc * 8 + h * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ra[j] = p[j];
+    };
+    auto load_b = [&](int k, int kc) {
+#pragma unroll
+        for (int j = 0; j < BPT; ++j) rb[j] = W4[((int64_t)k * 128 + kc * 32) * 32 + j * NTH + tid];
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < BPT; ++j) Bs4[buf][j * NTH + tid] = rb[j];
+    };
+    int k = kmask ? __builtin_ctz(kmask) : -1, kc = 0, nb = -1, nk = -1, nkc = 0, nbn = -1;
+    // one step: issue the loads of the next step, multiply the current one, publish the next weight chunk; returns false after the last step
+    auto step = [&](f32x4(&cur)[4], f32x4(&nxt)[4], const int buf) -> bool {
+        nk = k, nkc = kc + 1, nbn = nb;
+        if (nkc == 4) {
+            nkc = 0;
+            const unsigned rest = k + 1 < 32 ? kmask >> (k + 1) : 0u;
+            nk = rest ? k + 1 + __builtin_ctz(rest) : -1;
+            if (nk >= 0) nbn = s_nbr[nk * TM + wid * 32 + i32];
+        }
+        if (nk >= 0) {
+            load_a(nxt, nbn, nkc);
+            load_b(nk, nkc);
+        }
+        if ((wmask >> k) & 1u) {
+            const bool valid = nb >= 0;
+            const f32x4* Bp = &Bs4[buf][(h * 16) * 32 + i32];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const f32x4 b = Bp[s * 32];
+                const float a = valid ? cur[s >> 2][s & 3] : 0.f;
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[n], acc[n], 0, 0, 0);
+            }
+        }
+        if (nk < 0) return false;
+        store_b(buf ^ 1);
+        __syncthreads();
+        k = nk, kc = nkc, nb = nbn;
+        return true;
+    };
+    if (k >= 0) {
+        nb = s_nbr[k * TM + wid * 32 + i32];
+        load_a(raA, nb, 0);
+        load_b(k, 0);
+        store_b(0);
+        __syncthreads();
+        while (step(raA, raB, 0) && step(raB, raA, 1)) {
+        }
+    }
+    // epilogue: C/D layout of a 32x32 block: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); block n, lane col i32 <-> column 4*i32 + n
+    f32x4* Y4 = (f32x4*)Y;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t row = row0 + wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+        if (row < M_out) Y4[row * 32 + i32] = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Cin = Cout = 128 backward-weight: one workgroup per (row chunk, offset k) -> partial slab [128][128]
 // ---------------------------------------------------------------------------------------------
@@ -608,8 +721,12 @@ DD3D_API int dd3d_conv_fwd(const float* X, int64_t M_in, int Cin, const float* W
     } else {
         static const int dbg_tile = getenv("DD3D_CONV_TILE") ? atoi(getenv("DD3D_CONV_TILE")) : 0;
         static const int dbg_xcd = getenv("DD3D_CONV_XCD") ? atoi(getenv("DD3D_CONV_XCD")) : 0;
+        static const int dbg_rows = getenv("DD3D_CONV_ROWS") ? atoi(getenv("DD3D_CONV_ROWS")) : 1;
         const bool big = dbg_tile ? dbg_tile == 128 : M_out >= 128 * 512;
-        if (big) {
+        if (big && dbg_rows) {
+            const int64_t nt = ceil_div64(M_out, 128);
+            k_conv128_rows<4><<<dim3((unsigned)(ceil_div64(nt, 8) * 8)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, dbg_xcd);
+        } else if (big) {
             const int64_t nt = ceil_div64(M_out, 128);
             k_conv128<128, 2, 2><<<dim3((unsigned)(ceil_div64(nt, 8) * 8)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, dbg_xcd);
         } else if (dbg_tile ? dbg_tile == 64 : M_out >= 32 * 1024) {
