@@ -177,12 +177,10 @@ __global__ __launch_bounds__(256) void k_conv128(const float* __restrict__ X, co
 // order of the accumulation are those of k_conv128, so the two kernels give bit-identical results.
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_conv128_rows(const float* __restrict__ X, const float* __restrict__ W, const int* __restrict__ nbr, int64_t ld,
-                                                          int K, int M_bound, const int* __restrict__ m_dev, int mirror, float* __restrict__ Y, int xcd_remap,
-                                                          const int* __restrict__ perm) {
+                                                          int K, int M_bound, const int* __restrict__ m_dev, int mirror, float* __restrict__ Y, int xcd_remap) {
     constexpr int TM = NW * 32, NTH = NW * 64, BPT = 1024 / NTH;
     __shared__ f32x4 Bs4[2][32 * 32];
     __shared__ int s_nbr[27 * TM];
-    __shared__ int s_row[TM];  // output row of each tile slot: row0 + r, or perm[row0 + r] (rows grouped by neighbour pattern, see k_row_order)
     __shared__ unsigned s_kmask;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int i32 = lane & 31, h = lane >> 5;
@@ -193,15 +191,11 @@ __global__ __launch_bounds__(NW * 64) void k_conv128_rows(const float* __restric
     if (tile >= ntile || (xcd_remap && (int)(blockIdx.x >> 3) >= per_xcd)) return;
 
     if (tid == 0) s_kmask = 0;
-    if (tid < TM) {
-        const int64_t slot = row0 + tid;
-        s_row[tid] = slot < M_out ? (perm ? perm[slot] : (int)slot) : M_out;  // slots past the end (and rows a partial window maps past it) are dead
-    }
     __syncthreads();
     unsigned mymask = 0;
     for (int idx = tid; idx < K * TM; idx += NTH) {
         int k = idx / TM, r = idx - k * TM;
-        const int row = s_row[r];
+        int64_t row = row0 + r;
         int ks = mirror ? K - 1 - k : k;
         int v = row < M_out ? nbr[(int64_t)ks * ld + row] : -1;
         s_nbr[idx] = v;
@@ -282,180 +276,9 @@ __global__ __launch_bounds__(NW * 64) void k_conv128_rows(const float* __restric
     f32x4* Y4 = (f32x4*)Y;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int64_t row = s_row[wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+        const int64_t row = row0 + wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
         if (row < M_out) Y4[row * 32 + i32] = v;
-    }
-}
-
-// Independent-wave variant with a dynamic unit queue (the ordered path, dd3d_conv128_ordered).
-// Why: k_conv128 / k_conv128_rows are bound by WHERE the tiles land, not by the matrix pipe: all tiles of a launch are resident at
-// once (586 tiles of the cfg2 real batch on 768 slots), so a CU holds two or three of them and the launch lasts as long as three
-// tiles on one CU (3 x 36 steps x 4096 cycles = 192 us), whatever the other CUs do; skipping more zero rows does not shorten it.
-// Here a unit is one wave's 32 rows x 128 columns, nothing is shared between waves (the weight operands come straight from L2 into
-// registers: 127 TFLOP/s in tools/mfma_probe2, no LDS staging, no barrier), 2048 persistent waves (two per SIMD) pull units from an
-// atomic ticket counter, and the units arrive heaviest first (k_row_order sorts the rows of a window by neighbour count, then pattern,
-// and ticket t takes unit t / nwin of window t % nwin).  Same k-index assignment and accumulation order as k_conv128: bit-identical.
-constexpr int ROW_WIN = 8192;  // rows per sorting window of k_row_order (64 KB of 64-bit keys in LDS)
-
-__global__ __launch_bounds__(256, 2) void k_conv128_waves(const float* __restrict__ X, const float* __restrict__ W, const int* __restrict__ nbr, int64_t ld,
-                                                          int K, int M_bound, const int* __restrict__ m_dev, int mirror, float* __restrict__ Y,
-                                                          const int* __restrict__ perm, int* __restrict__ sched) {
-    __shared__ int s_nbr[4][27 * 32];
-    __shared__ int s_row[4][32];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int i32 = lane & 31, h = lane >> 5;
-    const int M_out = m_dev ? min(*m_dev, M_bound) : M_bound;
-    const int nwin = (M_out + ROW_WIN - 1) / ROW_WIN;
-    const int total = perm ? nwin * (ROW_WIN / 32) : (M_out + 31) / 32;
-    int* my_nbr = s_nbr[wid];
-    int* my_row = s_row[wid];
-    const f32x4* X4 = (const f32x4*)X;
-    const f32x4* W4 = (const f32x4*)W;
-    f32x4* Y4 = (f32x4*)Y;
-
-    for (;;) {
-        int t = 0;
-        if (lane == 0) t = atomicAdd(&sched[0], 1);
-        t = __shfl(t, 0, 64);
-        if (t >= total) break;
-        const int slot0 = perm ? (t % nwin) * ROW_WIN + (t / nwin) * 32 : t * 32;
-        if (slot0 >= M_out) continue;  // tail of the last, partial window
-        const int slot = slot0 + i32;
-        const int row = slot < M_out ? (perm ? perm[slot] : slot) : M_out;  // dead slots (and the dead rows a partial window sorts last) get M_out
-        __builtin_amdgcn_wave_barrier();  // the previous unit's epilogue has read my_row
-        if (h == 0) my_row[i32] = row;
-        unsigned wmask = 0;
-        {
-            int v[27];  // K == 27 (checked by the entry point): all table reads in flight together
-            const int rowc = min(row, M_out - 1);
-#pragma unroll
-            for (int k = 0; k < 27; ++k) v[k] = nbr[(int64_t)(mirror ? 26 - k : k) * ld + rowc];
-#pragma unroll
-            for (int k = 0; k < 27; ++k) {
-                if (row >= M_out) v[k] = -1;
-                if (h == 0) my_nbr[k * 32 + i32] = v[k];
-                if (__ballot(v[k] >= 0)) wmask |= 1u << k;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-
-        f32x16 acc[4];
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-        // Weight operands in two half-step register buffers (8 k-pairs each): every load is issued half a step (32 MFMAs) before its use.
-        f32x4 raA[4], raB[4], rb0[8], rb1[8];
-        auto load_a = [&](f32x4(&ra)[4], int nb, int kc) {
-            const f32x4* p = X4 + (int64_t)max(nb, 0) * 32 + kc * 8 + h * 4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ra[j] = p[j];
-        };
-        auto load_b = [&](f32x4(&rb)[8], int k, int kc, int half) {  // lane (i32, h): rows kc*32 + h*16 + half*8 + s of W[k], columns 4*i32 .. +3
-            const f32x4* p = W4 + ((int64_t)k * 128 + kc * 32 + h * 16 + half * 8) * 32 + i32;
-#pragma unroll
-            for (int s2 = 0; s2 < 8; ++s2) rb[s2] = p[s2 * 32];
-        };
-        int k = wmask ? __builtin_ctz(wmask) : -1, kc = 0, nb = -1, nk = -1, nkc = 0, nbn = -1;
-        auto step = [&](f32x4(&ca)[4], f32x4(&na)[4]) -> bool {
-            nk = k, nkc = kc + 1, nbn = nb;
-            if (nkc == 4) {
-                nkc = 0;
-                const unsigned rest = k + 1 < 32 ? wmask >> (k + 1) : 0u;
-                nk = rest ? k + 1 + __builtin_ctz(rest) : -1;
-                if (nk >= 0) nbn = my_nbr[nk * 32 + i32];
-            }
-            load_b(rb1, k, kc, 1);
-            if (nk >= 0) load_a(na, nbn, nkc);
-            const bool valid = nb >= 0;
-#pragma unroll
-            for (int s2 = 0; s2 < 8; ++s2) {
-                const float a = valid ? ca[s2 >> 2][s2 & 3] : 0.f;
-#pragma unroll
-                for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, rb0[s2][n], acc[n], 0, 0, 0);
-            }
-            if (nk >= 0) load_b(rb0, nk, nkc, 0);
-#pragma unroll
-            for (int s2 = 0; s2 < 8; ++s2) {
-                const float a = valid ? ca[2 + (s2 >> 2)][s2 & 3] : 0.f;
-#pragma unroll
-                for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, rb1[s2][n], acc[n], 0, 0, 0);
-            }
-            if (nk < 0) return false;
-            k = nk, kc = nkc, nb = nbn;
-            return true;
-        };
-        if (k >= 0) {
-            nb = my_nbr[k * 32 + i32];
-            load_a(raA, nb, 0);
-            load_b(rb0, k, 0, 0);
-            while (step(raA, raB) && step(raB, raA)) {
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t orow = my_row[(r & 3) + 8 * (r >> 2) + 4 * h];
-            const f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-            if (orow < M_out) Y4[orow * 32 + i32] = v;
-        }
-    }
-    // the last wave out re-arms the queue for the next launch (launches that share `sched` must be stream-ordered)
-    if (lane == 0) {
-        const int nwaves = (int)gridDim.x * 4;
-        if (atomicAdd(&sched[1], 1) == nwaves - 1) {
-            atomicExch(&sched[0], 0);
-            atomicExch(&sched[1], 0);
-        }
-    }
-}
-
-// Row order for k_conv128_waves: inside windows of ROW_WIN consecutive rows, the rows are sorted by (number of present offsets,
-// descending; the K-bit pattern of present offsets; row), so that the 32 rows a wave multiplies together mostly share one pattern -- the
-// offsets the pattern lacks are skipped for the whole unit -- and the units of a window come heaviest first.  Stroke digits at tensor
-// stride 2 have 73 % of the 9 in-plane neighbours: in cloud order a 32-row block executes 1.37x the algorithmic MFMA work, in this
-// order 1.06x.  A row's result does not depend on the rows it shares a block with (the skipped products are exact zeros), so any
-// order gives bit-identical output.  perm[w0 + j] = row at sorted position j of the window starting at w0; the positions of a partial
-// last window beyond the row count hold rows >= M (dead slots).
-__global__ __launch_bounds__(1024) void k_row_order(const int* __restrict__ nbr, int64_t ld, int K, int M_bound, const int* __restrict__ m_dev,
-                                                    int* __restrict__ perm) {
-    constexpr int WIN = ROW_WIN, PER = WIN / 1024;
-    __shared__ unsigned long long s_key[WIN];
-    const int tid = threadIdx.x;
-    const int M = m_dev ? min(*m_dev, M_bound) : M_bound;
-    const int w0 = blockIdx.x * WIN;
-    if (w0 >= M) return;
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        const int loc = j * 1024 + tid, row = w0 + loc;
-        unsigned mask = 0, light = 28;  // dead rows sort behind every live pattern
-        if (row < M) {
-#pragma unroll 9
-            for (int k = 0; k < K; ++k) mask |= (unsigned)(nbr[(int64_t)k * ld + row] >= 0) << k;
-            light = 27 - __popc(mask);
-        }
-        s_key[loc] = ((unsigned long long)light << 40) | ((unsigned long long)mask << 13) | (unsigned)loc;
-    }
-    __syncthreads();
-    for (int k = 2; k <= WIN; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-#pragma unroll
-            for (int c2 = 0; c2 < PER / 2; ++c2) {
-                const int c = c2 * 1024 + tid;
-                const int i = ((c & ~(j - 1)) << 1) | (c & (j - 1)), p = i | j;
-                const unsigned long long a = s_key[i], b = s_key[p];
-                const bool up = (i & k) == 0;
-                if ((a > b) == up) {
-                    s_key[i] = b;
-                    s_key[p] = a;
-                }
-            }
-            __syncthreads();
-        }
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        const int loc = j * 1024 + tid;
-        if (w0 + loc < M_bound) perm[w0 + loc] = w0 + (int)(s_key[loc] & (unsigned)(WIN - 1));
     }
 }
 
@@ -902,7 +725,7 @@ DD3D_API int dd3d_conv_fwd(const float* X, int64_t M_in, int Cin, const float* W
         const bool big = dbg_tile ? dbg_tile == 128 : M_out >= 128 * 512;
         if (big && dbg_rows) {
             const int64_t nt = ceil_div64(M_out, 128);
-            k_conv128_rows<4><<<dim3((unsigned)(ceil_div64(nt, 8) * 8)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, dbg_xcd, nullptr);
+            k_conv128_rows<4><<<dim3((unsigned)(ceil_div64(nt, 8) * 8)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, dbg_xcd);
         } else if (big) {
             const int64_t nt = ceil_div64(M_out, 128);
             k_conv128<128, 2, 2><<<dim3((unsigned)(ceil_div64(nt, 8) * 8)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, dbg_xcd);
@@ -915,35 +738,6 @@ DD3D_API int dd3d_conv_fwd(const float* X, int64_t M_in, int Cin, const float* W
             k_conv128<32, 1, 4><<<dim3((unsigned)(ceil_div64(nt, 8) * 8)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, dbg_xcd);
         }
     }
-    DD3D_CHECK_LAUNCH();
-    return 0;
-}
-
-// Row order for dd3d_conv128_ordered: perm[M] (int32), rows grouped by neighbour pattern inside windows of 8192 rows, heaviest first.
-// One order serves the forward and the mirrored (backward-data) launch over the same kernel map: mirroring permutes the bits of every
-// pattern alike.
-DD3D_API int dd3d_conv_row_order(const int32_t* nbr, int64_t ld, int K, int64_t M, const int32_t* m_dev, int32_t* perm, void* stream) {
-    if (M < 0 || K <= 0 || K > 27 || ld < M) return DD3D_EARG;
-    if (M >= (1ll << 31) - ROW_WIN) return DD3D_ESIZE;
-    if (M == 0) return 0;
-    if (!nbr || !perm) return DD3D_EARG;
-    k_row_order<<<dim3((unsigned)ceil_div64(M, ROW_WIN)), 1024, 0, (hipStream_t)stream>>>(nbr, ld, K, (int)M, m_dev, perm);
-    DD3D_CHECK_LAUNCH();
-    return 0;
-}
-
-// dd3d_conv_fwd for Cin = Cout = 128 on the independent-wave kernel: 32-row units in the order of `perm` (dd3d_conv_row_order over the
-// same nbr / M / m_dev; nullable = row order), pulled from a ticket queue.  Same result as dd3d_conv_fwd, bit for bit.  sched: 2 ints
-// of device memory, zero before the first use; every call leaves them zero.  Calls that share `sched` must not overlap.
-DD3D_API int dd3d_conv128_ordered(const float* X, int64_t M_in, const float* W, const int32_t* nbr, int64_t ld, int K, int64_t M_out, const int32_t* m_dev,
-                                  int mirror, const int32_t* perm, int32_t* sched, float* Y, void* stream) {
-    if (M_out < 0 || M_in < 0 || K != 27 || ld < M_out) return DD3D_EARG;
-    if (M_out >= (1ll << 31) / 128 * 16) return DD3D_ESIZE;
-    if (M_out == 0) return 0;
-    if (!X || !W || !nbr || !Y || !sched) return DD3D_EARG;
-    const int64_t units = ceil_div64(M_out, 32);
-    const int64_t wgs = units < 4 * 512 ? ceil_div64(units, 4) : 512;  // two workgroups of four waves per CU
-    k_conv128_waves<<<dim3((unsigned)wgs), 256, 0, (hipStream_t)stream>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, perm, sched);
     DD3D_CHECK_LAUNCH();
     return 0;
 }

@@ -120,21 +120,6 @@ int dd3d_cloud_maps(const float* coords, const int32_t* pt_off, int B, int max_p
 int dd3d_conv_fwd(const float* X, int64_t M_in, int Cin, const float* W, int Cout, const int32_t* nbr, int64_t ld, int K, int64_t M_out,
                   const int32_t* m_dev, int mirror, float* Y, void* stream);
 
-/* Row order for dd3d_conv128_ordered: perm[M] int32; inside windows of 8192 rows the rows are sorted by (number of present offsets,
- * descending; the K-bit pattern of present offsets; row), so that the 32 rows one wave multiplies together share a pattern -- absent
- * offsets are skipped for the whole block -- and heavy blocks are scheduled first.  One order serves the forward and the mirrored
- * launch over the same map.  No counterpart in MinkowskiEngine (its gather-GEMM-scatter compacts per offset instead); serves
- * MEConv.py:224 like dd3d_conv_fwd. */
-int dd3d_conv_row_order(const int32_t* nbr, int64_t ld, int K, int64_t M, const int32_t* m_dev, int32_t* perm, void* stream);
-
-/* dd3d_conv_fwd for Cin = Cout = 128, K = 27 on independent waves: 32-row units taken in the order of `perm` (nullable = row order)
- * from a ticket queue, weights straight from L2.  Bit-identical to dd3d_conv_fwd (a row's sum does not depend on the rows it shares
- * a block with).  sched: 2 ints of device memory, zero before the first use; every call leaves them zero; calls sharing it must be
- * stream-ordered.
- * replaces: ConvolutionForwardGPU / ConvolutionBackwardGPU (input gradient, mirror = 1 with the transposed kernel), MEConv.py:224 */
-int dd3d_conv128_ordered(const float* X, int64_t M_in, const float* W, const int32_t* nbr, int64_t ld, int K, int64_t M_out, const int32_t* m_dev,
-                         int mirror, const int32_t* perm, int32_t* sched, float* Y, void* stream);
-
 /* dX[M,Cin] of a stride-1 convolution.  Cin = 128: pass the transposed kernel [K,Cout,Cin]; Cin = 3: pass W itself.
  * replaces: ConvolutionBackwardGPU (input gradient) reached by torch.autograd.grad / loss.backward, mnist_distill.py:349,359,365 */
 int dd3d_conv_bwd_data(const float* dY, int64_t M, const int32_t* m_dev, int Cout, const float* W_or_Wt, int Cin, const int32_t* nbr, int64_t ld,

@@ -32,26 +32,5 @@ for name, coords, B in (("real", b["coordinates"], 2560), ("syn", sc, 100)):
     for _ in range(n): run()
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / n * 1e3
-    # ordered variant: rows grouped by neighbour pattern (dd3d_conv_row_order), must be bit-identical
-    perm = torch.empty(M, dtype=torch.int32, device=dev)
-    Y2 = torch.empty_like(Y)
-    sched = torch.zeros(2, dtype=torch.int32, device=dev)
-    use_perm = True
-    def order():
-        L.call("dd3d_conv_row_order", L.ptr(nbr), ld, 27, M, None, L.ptr(perm), L.stream())
-    def run2():
-        L.call("dd3d_conv128_ordered", L.ptr(X), M, L.ptr(W), L.ptr(nbr), ld, 27, M, None, 0, L.ptr(perm) if use_perm else None, L.ptr(sched), L.ptr(Y2), L.stream())
-    order(); run2(); torch.cuda.synchronize()
-    assert sorted(perm.tolist()) == list(range(M)), "perm is not a permutation"
-    assert torch.equal(Y, Y2), "ordered conv differs"
-    for f, tag, up in ((order, "row_order", True), (run2, "waves conv, ordered", True), (run2, "waves conv, row order", False)):
-        use_perm = up
-        Y2.zero_(); f(); torch.cuda.synchronize()
-        assert tag == "row_order" or torch.equal(Y, Y2), tag + " differs"
-        e0.record()
-        for _ in range(n): f()
-        e1.record(); torch.cuda.synchronize()
-        print(f"   {tag}: {e0.elapsed_time(e1) / n * 1e3:8.1f} us")
-    assert int(sched.abs().sum()) == 0
     act = int((nbr[:, :M] >= 0).any(1).sum())
     print(f"{name}: M={M} pairs={pairs} active offsets={act} density={pairs/(M*act):.2f}  {us:8.1f} us  {2*pairs*128*128/us/1e6:6.1f} TFLOP/s (alg)")
