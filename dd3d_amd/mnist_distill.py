@@ -1,7 +1,7 @@
 """The gradient-matching loop of the reference's ``mnist_distill.py`` (:294-374) on the MI355X kernels.
 
 ``Distiller.outer_step()`` is one iteration of the reference loop without evaluation / logging / export (SURVEY.md section 8a
-row a1): clamp (:311-317), per-class real and synthetic forward + gradients (:335-359), ``match_loss`` (:360), backward into the
+row a1; those live in ``evaluation.py`` / ``export.py`` and are driven by ``main``): clamp (:311-317), per-class real and synthetic forward + gradients (:335-359), ``match_loss`` (:360), backward into the
 synthetic xyz (:365) and the SGD(momentum 0.5) step (:369).  Run as a script it takes the reference's flags
 (``--log/--no-log --exp --pytorch``) and INI keys, on MNIST-shaped synthetic digits (no dataset download offline).
 """
@@ -100,24 +100,56 @@ class Distiller:
 
 
 def main(argv=None):
+    """The reference's ``__main__`` (mnist_distill.py:251-410) on MNIST-shaped synthetic digits: matching steps, the evaluation block at
+    the reference's iterations (:276, :320-330), checkpoint + .ply export every ``save_cad_every`` iterations (:383-402)."""
+    import copy
+    import math
+    import os
+
+    from . import evaluation, export
+    from .models.MNIST import ConvNet
     from .synthetic import mnist3d_like
+    from .utils.Mnist2D import TensorDataset
     settings.init(argv)
     dev = settings.device
     torch.random.manual_seed(int(time.time() * 1000) % 100000)
     images_all, _labels, indices_class = mnist3d_like(10, 512, seed=0)
+    test_images, test_labels, _ = mnist3d_like(10, 100, seed=1)  # held-out digits standing in for the MNIST test split
+    testloader = torch.utils.data.DataLoader(TensorDataset(test_images.reshape(-1, 1, 28, 28), test_labels), batch_size=256, shuffle=False)
     network = MEPytorch(3, 10) if settings.Pyt else MEConvExp(in_channel=3, out_channel=10)
     settings.log_string(network)
     d = Distiller(images_all, indices_class, network, ipc=settings.cad_per_class, num_points=settings.num_points,
                   batch_size=settings.modelconfig.getint("batch_size"), dist_opt=settings.modelconfig.get("dist_opt"),
                   dist_lr=settings.modelconfig.getfloat("dist_lr"), device=dev)
     total = settings.distillationconfig.getint("total_iterations")
-    log_loss = []
+    eval_iteration_pool = [0, 250, total // 4, total // 2, total // 4 + total // 2, total - 1]
+    export_cad_dir = os.path.join(settings.logging_folder_name, settings.distillationconfig.get("export_folder_name"))
+    os.makedirs(export_cad_dir, exist_ok=True)
+    ckpt_dir = settings.distillationconfig.get("distillation_checkpoint_dir")
+    os.makedirs(ckpt_dir, exist_ok=True)
+    log_loss, least_loss, loss_value = [], math.inf, math.inf
     for iteration in range(total):
+        if iteration in eval_iteration_pool:
+            d.clamp()
+            settings.log_string("----- Evaluation -----\nModel_train = Convnet2D\nIteration: " + str(iteration))
+            for it_eval in range(5):
+                classifier_network = ConvNet(1, 10, 128, 3, "relu", "instancenorm", "avgpooling")
+                evaluation.evaluate_synset(it_eval, classifier_network, copy.deepcopy(d.image_syn.detach()), copy.deepcopy(d.label_syn),
+                                           testloader, iteration, export_cad_dir=export_cad_dir)
         loss = d.outer_step()
         log_loss.append(loss.item() / 10)
         if iteration % 100 == 0:
-            settings.log_string("Iteration: %d Loss matched is %s" % (iteration, sum(log_loss) / len(log_loss)))
+            loss_value = sum(log_loss) / len(log_loss)
+            settings.log_string("Iteration: %d Loss matched is %s" % (iteration, loss_value))
             log_loss = []
+        if iteration % settings.distillationconfig.getint("save_cad_every") == 0:
+            if loss_value <= least_loss:
+                least_loss = loss_value
+                savepath = os.path.join(ckpt_dir, settings.exp_file_name + ".pth")
+                settings.log_string("Saving at %s" % savepath)
+                export.save_checkpoint(savepath, iteration, least_loss, network, d.optimizer_img, d.image_syn, d.label_syn)
+            settings.log_string("Exporting Point Cloud")
+            settings.save_cad(d.image_syn, export_cad_dir, iteration, normalize=False)
 
 
 if __name__ == "__main__":

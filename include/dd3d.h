@@ -235,6 +235,15 @@ int dd3d_match_loss_bwd(const dd3d_gseg* segs, int n, int G, int metric, const f
 int dd3d_sgd_momentum_clamp(float* x, const float* grad, float* mom, int64_t n, float lr, float momentum, int first_step, int do_clamp, float lo,
                             float hi, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * (6) evaluation block: synthetic clouds -> occupancy images
+ * ------------------------------------------------------------------------------------------------------------------- */
+
+/* img[cloud, 0, trunc(xyz[1]), trunc(xyz[2])] = 1 for every point; img is [n_clouds,1,H,W] fp32 and is NOT cleared here (the caller
+ * passes zeros, as the reference does).  Negative indices count from the end (Python indexing); an index outside the image sets
+ * bit 0 of *err (the reference raises IndexError).  replaces: populate_img, mnist_distill.py:163-168 */
+int dd3d_populate_img(const float* xyz, int64_t n_clouds, int64_t pts_per_cloud, int H, int W, float* img, int32_t* err, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -214,3 +214,20 @@ def matching_step(network, image_syn, real_images_per_class, ipc, dist_opt="modm
         optimizer.step()
     return {"loss": loss.detach(), "per_class": torch.stack(per_class), "gw_real": gwr_all, "gw_syn": gws_all,
             "grad": grad, "logits": logits_all}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Evaluation block
+# ------------------------------------------------------------------------------------------------------------------
+def populate_img(occ_grid: torch.Tensor, img_array: torch.Tensor) -> torch.Tensor:
+    """mnist_distill.py:163-168: every point switches on pixel (int(p[1]), int(p[2])) of its cloud's image; the conversion truncates
+    toward zero and the assignment follows Python indexing (negative = from the end, out of range = IndexError).  Pinned by
+    tests/golden/g6_eval.npz (the reference's own function on seeded clouds)."""
+    h, w = img_array.shape[2], img_array.shape[3]
+    for idx, cloud in enumerate(occ_grid.detach().cpu().numpy()):
+        for p in cloud:
+            y, x = int(p[1]), int(p[2])
+            if not (-h <= y < h and -w <= x < w):
+                raise IndexError("index out of range")
+            img_array[idx, 0, y, x] = 1
+    return img_array

@@ -35,3 +35,13 @@ def det_state_dict(module: torch.nn.Module, tag: str):
 def sample_idx(numel: int, tag: str, k: int = 64) -> np.ndarray:
     rng = np.random.default_rng(zlib.crc32(("idx" + tag).encode()))
     return rng.integers(0, numel, size=min(k, numel))
+
+
+def eval_inputs():
+    """Seeded inputs of the evaluation-block fixture g6_eval.npz: 6 clouds of 40 points in [0, 28), 12 binary 28x28 images, labels."""
+    clouds = det_tensor((6, 40, 3), "g6.clouds").abs() * 9.0
+    clouds = clouds.clamp(0, 27.99)
+    clouds[:, :, 0] = 0
+    imgs = (det_tensor((12, 1, 28, 28), "g6.imgs") > 0.8).float()
+    labels = torch.arange(12) % 10
+    return clouds, imgs, labels

@@ -14,6 +14,9 @@ Fixtures (data only; inputs are regenerated from tests/detgen.py seeds by the te
   g3_mepytorch.npz    reference MEPytorch: one matching step (2 classes x 4 real, ipc 2)
   g4_meconvexp.npz    reference MEConvExp topology over the ME restatement: one matching step, modmse + ours
   g5_ctor.npz         constructor parameter names / shapes / order
+  g6_eval.npz         evaluation block: reference models/MNIST.py ConvNet (names, shapes, seeded forward) and
+                      mnist_distill.py populate_img / augment / epoch on seeded inputs (open3d, torchinfo, torchvision.utils are
+                      name-only stand-ins: none of them is reached by these functions)
 
 usage:  python tests/golden/make_golden.py
 """
@@ -30,7 +33,7 @@ REF = "/root/reference"
 sys.path.insert(0, REPO)
 
 from oracle import minkowski_ref as MEref  # noqa: E402
-from tests.detgen import det_state_dict, det_tensor, sample_idx  # noqa: E402
+from tests.detgen import det_state_dict, det_tensor, eval_inputs, sample_idx  # noqa: E402
 from dd3d_amd.synthetic import init_synthetic, stroke_digits  # noqa: E402
 
 
@@ -195,6 +198,52 @@ def g5(MEConv):
     np.savez_compressed(os.path.join(HERE, "g5_ctor.npz"), **out)
 
 
+def g6(settings):
+    for name in ("open3d", "torchinfo"):
+        m = types.ModuleType(name)
+        m.summary = lambda *a, **k: None
+        sys.modules[name] = m
+    tvu = types.ModuleType("torchvision.utils")
+    tvu.save_image = lambda *a, **k: None
+    tvu.make_grid = lambda *a, **k: None
+    sys.modules["torchvision.utils"] = tvu
+    sys.modules["torchvision"].utils = tvu
+    import mnist_distill as md   # the reference's loop module; its __main__ block does not run
+    from models.MNIST import ConvNet
+    out = {}
+    torch.manual_seed(0)
+    net = ConvNet(1, 10, 128, 3, "relu", "instancenorm", "avgpooling")
+    out["convnet.names"] = np.array([n for n, _ in net.named_parameters()])
+    out["convnet.shapes"] = np.array([str(tuple(p.shape)) for p in net.parameters()])
+    out["convnet.sd_keys"] = np.array(list(net.state_dict().keys()))
+    out["convnet.repr"] = np.array(repr(net))
+    clouds, imgs, labels = eval_inputs()
+    net.eval()
+    with torch.no_grad():
+        out["convnet.out"] = net(imgs).numpy()
+    # populate_img (mnist_distill.py:163-168)
+    canvas = torch.zeros(clouds.shape[0], 1, 28, 28)
+    out["populate.img"] = md.populate_img(clouds, canvas).numpy()
+    # augment (mnist_distill.py:65-124): one of crop / scale / rotate per image, numpy global RNG
+    np.random.seed(5)
+    torch.manual_seed(5)
+    out["augment.out"] = md.augment(imgs.clone(), torch.device("cpu")).numpy()
+    # epoch (mnist_distill.py:126-158): three training epochs + one test epoch, SGD as evaluate_synset :176
+    settings.device = torch.device("cpu")
+    np.random.seed(7)
+    torch.manual_seed(7)
+    net = ConvNet(1, 10, 128, 3, "relu", "instancenorm", "avgpooling")
+    opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=0.0005)
+    crit = torch.nn.CrossEntropyLoss()
+    from utils.Mnist2D import TensorDataset
+    loader = torch.utils.data.DataLoader(TensorDataset(imgs.clone(), labels), batch_size=256, shuffle=True, num_workers=0)
+    rec = [md.epoch("train", loader, net, opt, crit, aug=False) for _ in range(3)]
+    rec.append(md.epoch("test", loader, net, opt, crit, aug=False))
+    out["epoch.loss_acc"] = np.array(rec, dtype=np.float64)
+    out["epoch.w_norms"] = np.array([p.detach().norm().item() for p in net.parameters()])
+    np.savez_compressed(os.path.join(HERE, "g6_eval.npz"), **out)
+
+
 def main():
     settings = install_stubs()
     sys.path.insert(0, REF)
@@ -207,6 +256,7 @@ def main():
     run_model_fixture(settings, Mnist2D, MEConv, dl, MEConv.MEPytorch, True, "g3_mepytorch.npz", ["modmse", "ours"])
     run_model_fixture(settings, Mnist2D, MEConv, dl, MEConv.MEConvExp, False, "g4_meconvexp.npz", ["modmse", "ours"])
     g5(MEConv)
+    g6(settings)
     print("golden fixtures written to", HERE)
 
 
