@@ -186,39 +186,87 @@ __device__ CloudCounts build_cloud(CloudSmem<NMAX>& S, const float4* __restrict_
 }
 
 // ---- pass A: voxel counts of every cloud at strides 1, 2, 4 + per-group minimum corner of the stride-4 coordinates ----
+// Counting needs none of the ordered outputs of build_cloud: the number of distinct stride-s coordinates of the POINTS equals the number
+// of stride-s voxels (a stride-2 voxel is the stride-2 coordinate of some stride-1 voxel, which is the coordinate of some point), and
+// it is the number of inserts that found their slot empty.  So the three levels are three independent hash-set inserts per point
+// -- two barriers in all instead of the ~40 of the ordered build -- and the minimum corner folds over the points' stride-4 coordinates.
 template <int NMAX>
 __global__ __launch_bounds__(CT) void k_cloud_count(const float4* __restrict__ coords, const int* __restrict__ pt_off, int B,
                                                     const int* __restrict__ cloud_group, int* __restrict__ cnt /*[3][B]*/, int* gmin /*[G][3]*/,
                                                     int* err) {
+    constexpr int HC = CloudSmem<NMAX>::HC;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     CloudSmem<NMAX>& S = *reinterpret_cast<CloudSmem<NMAX>*>(smem_raw);
     const int b = blockIdx.x, tid = threadIdx.x;
     const int p0 = pt_off[b];
-    int n;
-    const CloudCounts c = build_cloud<NMAX>(S, coords, p0, pt_off[b + 1] - p0, b, err, &n);
-    if (tid == 0) {
-        cnt[b] = c.m1;
-        cnt[B + b] = c.m2;
-        cnt[2 * B + b] = c.m4;
+    int n = pt_off[b + 1] - p0;
+    if (n > NMAX) {
+        n = NMAX;
+        if (tid == 0) atomicOr(err, 8);
     }
-    if (gmin) {
-        const int big = 0x7F7F7F7F;
-        int a = big, d = big, e = big;
-        for (int t = tid; t < c.m4; t += CT) {
-            const int4 u = S.U4[t];
-            a = min(a, u.y); d = min(d, u.z); e = min(e, u.w);
+    for (int i = tid; i < HC; i += CT) S.tab1[i] = S.tab2[i] = S.tab4[i] = -1;
+    if (tid < 6) S.s_w[tid] = tid < 3 ? 0 : 0x7F7F7F7F;
+    bool bad = false;
+    for (int i = tid; i < n; i += CT) {
+        const float4 c = coords[p0 + i];
+        const int4 k = make_int4((int)floorf(c.x), (int)floorf(c.y), (int)floorf(c.z), (int)floorf(c.w));
+        bad |= k.x != b;
+        S.q[i] = k;
+    }
+    if (bad) atomicOr(err, 1);
+    __syncthreads();
+    const int big = 0x7F7F7F7F;
+    int a = big, d = big, e = big;
+    int won1 = 0, won2 = 0, won4 = 0;
+    for (int i = tid; i < n; i += CT) {
+        const int4 k1 = S.q[i], k2 = stride_coord(k1, 2), k4 = stride_coord(k1, 4);
+        a = min(a, k4.y); d = min(d, k4.z); e = min(e, k4.w);
+        uint32_t h = hash_coord(k1) & (HC - 1);
+        for (;;) {
+            const int old = atomicCAS(&S.tab1[h], -1, i);
+            if (old == -1) { ++won1; break; }
+            if (coord_eq(S.q[old], k1)) break;
+            h = (h + 1) & (HC - 1);
         }
+        h = hash_coord(k2) & (HC - 1);
+        for (;;) {
+            const int old = atomicCAS(&S.tab2[h], -1, i);
+            if (old == -1) { ++won2; break; }
+            if (coord_eq(stride_coord(S.q[old], 2), k2)) break;
+            h = (h + 1) & (HC - 1);
+        }
+        h = hash_coord(k4) & (HC - 1);
+        for (;;) {
+            const int old = atomicCAS(&S.tab4[h], -1, i);
+            if (old == -1) { ++won4; break; }
+            if (coord_eq(stride_coord(S.q[old], 4), k4)) break;
+            h = (h + 1) & (HC - 1);
+        }
+    }
+    won1 = wave_sum_i(won1); won2 = wave_sum_i(won2); won4 = wave_sum_i(won4);
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            a = min(a, __shfl_xor(a, o, 64));
-            d = min(d, __shfl_xor(d, o, 64));
-            e = min(e, __shfl_xor(e, o, 64));
-        }
-        if ((tid & 63) == 0 && a != big) {
-            const int g = cloud_group ? cloud_group[b] : 0;
-            atomicMin(&gmin[g * 3 + 0], a);
-            atomicMin(&gmin[g * 3 + 1], d);
-            atomicMin(&gmin[g * 3 + 2], e);
+    for (int o = 32; o > 0; o >>= 1) {
+        a = min(a, __shfl_xor(a, o, 64));
+        d = min(d, __shfl_xor(d, o, 64));
+        e = min(e, __shfl_xor(e, o, 64));
+    }
+    if ((tid & 63) == 0) {
+        atomicAdd(&S.s_w[0], won1);
+        atomicAdd(&S.s_w[1], won2);
+        atomicAdd(&S.s_w[2], won4);
+        atomicMin(&S.s_w[3], a);
+        atomicMin(&S.s_w[4], d);
+        atomicMin(&S.s_w[5], e);
+    }
+    __syncthreads();
+    if (tid < 3) {
+        cnt[tid * B + b] = S.s_w[tid];
+        // one global atomic per cloud and axis, and only when it can lower the group's corner (most clouds share it): the values only
+        // decrease, so a stale read costs an unnecessary atomic at worst
+        const int m = S.s_w[3 + tid];
+        if (gmin && m != big) {
+            int* dst = &gmin[(cloud_group ? cloud_group[b] : 0) * 3 + tid];
+            if (m < __atomic_load_n(dst, __ATOMIC_RELAXED)) atomicMin(dst, m);
         }
     }
 }
