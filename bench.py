@@ -174,16 +174,16 @@ def main():
         flops = [2.0 * p * 128 * 128 for p in pairs]
         avg_ms = sum(ms) / max(len(ms), 1)
         avg_flop = sum(flops) / max(len(flops), 1)
-        roof = {"bound": "mfma", "kernel": "k_conv128 (dd3d_conv_fwd, Cin=Cout=128, fp32 MFMA 32x32x2)", "achieved": avg_flop / (avg_ms * 1e-3) / 1e12,
+        roof = {"bound": "mfma", "kernel": "k_conv128_rows<4> (dd3d_conv_fwd on the merged batch, Cin=Cout=128, fp32 MFMA 32x32x2)", "achieved": avg_flop / (avg_ms * 1e-3) / 1e12,
                 "peak": 157.3, "unit": "TFLOP/s", "traffic": None, "launches": len(ms), "avg_launch_us": avg_ms * 1e3,
                 "avg_pairs_per_launch": sum(pairs) / max(len(pairs), 1)}
         roof["frac"] = roof["achieved"] / roof["peak"]
         # HBM bytes per launch of this kernel: PMC counters cannot be read from inside the process, so the figure comes from the
         # committed rocprofv3 --pmc passes of this same command (tools/pmc.sh -> tools/pmc_to_json.py), corrected as the file says
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv128.json")
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv128_rows.json")
         if args.path != "dropin" and args.config == "cfg2" and args.ipc == IPC and os.path.exists(pmc):
-            roof["traffic"] = json.load(open(pmc))["traffic_bytes_per_launch_avg_real_syn"]
-            roof["traffic_source"] = "profiles/r01_pmc_conv128.json"
+            roof["traffic"] = json.load(open(pmc))["traffic_bytes_per_launch"]
+            roof["traffic_source"] = "profiles/r01_pmc_conv128_rows.json"
         out = {"metric": METRIC, "value": args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
                "data": "synthetic", "config": {"workload": (f"{args.config}: MNIST-3D-shaped stroke digits, {NUM_CLASSES} classes x {REAL_PER_CLASS} real clouds, "

@@ -522,6 +522,9 @@ __global__ __launch_bounds__(256) void k_conv3_fwd(const float* __restrict__ X, 
 }
 
 // dX[i][ci] = sum_k sum_co dY[nbr[K-1-k][i]][co] * W[k][ci][co]
+// Half a wave per row (32 lanes x float4 = the 128 channels of a gathered dY row), 8 rows per workgroup pass.  The launch is small (the
+// synthetic prefix only: the real batch needs no input gradient of the first layer) and latency-bound, so the 27 gathers of a row are
+// issued three at a time with clamped addresses (no branch between them) and a workgroup makes ONE pass when the grid allows it.
 __global__ __launch_bounds__(256) void k_conv3_bwd_data(const float* __restrict__ dY, const float* __restrict__ W, const int* __restrict__ nbr, int64_t ld,
                                                         int K, int M_bound, const int* __restrict__ m_dev, int rows_per_block, float* __restrict__ dX) {
     __shared__ f32x4 Ws4[27 * 3 * 32];
@@ -539,14 +542,23 @@ __global__ __launch_bounds__(256) void k_conv3_bwd_data(const float* __restrict_
         bool live = row < M;
         int mynb = (live && c4 < K) ? nbr[(int64_t)(K - 1 - c4) * ld + row] : -1;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-        for (int k = 0; k < K; ++k) {
-            int nb = __shfl(mynb, k, 32);
-            if (nb >= 0) {
-                f32x4 d = D4[(int64_t)nb * 32 + c4];
-                f32x4 w0 = Ws4[(k * 3 + 0) * 32 + c4], w1 = Ws4[(k * 3 + 1) * 32 + c4], w2 = Ws4[(k * 3 + 2) * 32 + c4];
-                s0 += d[0] * w0[0] + d[1] * w0[1] + d[2] * w0[2] + d[3] * w0[3];
-                s1 += d[0] * w1[0] + d[1] * w1[1] + d[2] * w1[2] + d[3] * w1[3];
-                s2 += d[0] * w2[0] + d[1] * w2[1] + d[2] * w2[2] + d[3] * w2[3];
+        for (int k0 = 0; k0 < 27; k0 += 3) {
+            int nb[3];
+            f32x4 d[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                nb[j] = __shfl(mynb, k0 + j, 32);
+                d[j] = D4[(int64_t)max(nb[j], 0) * 32 + c4];
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if (nb[j] >= 0) {  // accumulation order = ascending k, as before
+                    const int k = k0 + j;
+                    const f32x4 w0 = Ws4[(k * 3 + 0) * 32 + c4], w1 = Ws4[(k * 3 + 1) * 32 + c4], w2 = Ws4[(k * 3 + 2) * 32 + c4];
+                    s0 += d[j][0] * w0[0] + d[j][1] * w0[1] + d[j][2] * w0[2] + d[j][3] * w0[3];
+                    s1 += d[j][0] * w1[0] + d[j][1] * w1[1] + d[j][2] * w1[2] + d[j][3] * w1[3];
+                    s2 += d[j][0] * w2[0] + d[j][1] * w2[1] + d[j][2] * w2[2] + d[j][3] * w2[3];
+                }
             }
         }
 #pragma unroll
@@ -749,7 +761,7 @@ DD3D_API int dd3d_conv_bwd_data(const float* dY, int64_t M, const int32_t* m_dev
     if (M < 0 || K != 27 || ld < M || Cout != 128 || Cin != 3) return DD3D_EARG;
     if (M == 0) return 0;
     if (!dY || !W_or_Wt || !nbr || !dX) return DD3D_EARG;
-    const int rpb = 64;
+    const int rpb = M <= 8 * 8192 ? 8 : 64;  // one pass per workgroup while the grid stays small
     k_conv3_bwd_data<<<dim3((unsigned)ceil_div64(M, rpb)), 256, 0, (hipStream_t)stream>>>(dY, W_or_Wt, nbr, ld, K, (int)M, m_dev, rpb, dX);
     DD3D_CHECK_LAUNCH();
     return 0;

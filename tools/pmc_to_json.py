@@ -1,5 +1,6 @@
-"""profiles/<name>.json from a tools/pmc.sh run: HBM traffic per launch of the roofline kernel (dd3d_conv_fwd, Cin=128 forward = the
-real-batch launch on k_conv128<128,2,2> and the synthetic-batch launch on k_conv128<64,1,4>).  Units per the MI355X guide: rocprofv3
+"""profiles/<name>.json from a tools/pmc.sh run: HBM traffic per launch of the roofline kernel (the Cin = Cout = 128 sparse convolution
+of the merged batch on k_conv128_rows<4>: two launches per step, forward and mirrored backward-data, same rows and pairs; the
+synthetic-prefix second-order launch runs on k_conv128<32,1,4> and is listed separately).  Units per the MI355X guide: rocprofv3
 FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE tallies 128-B read requests at 64 B, so it is doubled.
 usage: pmc_to_json.py <pmc dir> <out.json>"""
 import csv, glob, json, sys, collections
@@ -9,14 +10,14 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f"{d}/{c}/*/*counter_collection.csv")[0]
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == c and "k_conv128<" in r["Kernel_Name"]:
-            key = "real(128-row tiles)" if "<128" in r["Kernel_Name"] else "syn(64-row tiles)"
+        if r["Counter_Name"] == c and "k_conv128" in r["Kernel_Name"] and "bww" not in r["Kernel_Name"]:
+            key = "merged batch (k_conv128_rows<4>)" if "k_conv128_rows" in r["Kernel_Name"] else "synthetic prefix (k_conv128<32,1,4>)"
             agg[key][0] += 1
             agg[key][1] += float(r["Counter_Value"])
     res[c] = {k: v[1] / v[0] for k, v in agg.items()}
 per = {k: (2 * res["FETCH_SIZE"][k] + res["WRITE_SIZE"][k]) * 1024 for k in res["FETCH_SIZE"]}
-j = {"kernel": "k_conv128 (dd3d_conv_fwd, Cin=Cout=128)", "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (tools/pmc.sh)",
+j = {"kernel": "k_conv128_rows<4> (dd3d_conv_fwd, Cin=Cout=128)", "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (tools/pmc.sh)",
      "kib_per_launch_raw": res, "correction": "FETCH_SIZE x2 on gfx950 (128-B requests tallied at 64 B), WRITE_SIZE exact; KiB -> bytes",
-     "hbm_bytes_per_launch": per, "traffic_bytes_per_launch_avg_real_syn": sum(per.values()) / len(per)}
+     "hbm_bytes_per_launch": per, "traffic_bytes_per_launch": per.get("merged batch (k_conv128_rows<4>)")}
 json.dump(j, open(out, "w"), indent=1)
 print(json.dumps(j, indent=1))
