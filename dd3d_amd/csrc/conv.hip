@@ -741,7 +741,7 @@ DD3D_API int dd3d_conv_fwd(const float* X, int64_t M_in, int Cin, const float* W
         } else if (big) {
             const int64_t nt = ceil_div64(M_out, 128);
             k_conv128<128, 2, 2><<<dim3((unsigned)(ceil_div64(nt, 8) * 8)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, dbg_xcd);
-        } else if (dbg_tile ? dbg_tile == 64 : M_out >= 32 * 1024) {
+        } else if (dbg_tile == 64) {  // measured (tools/convsweep.py): never the fastest -- 32-row tiles win below ~50k rows, 128-row tiles above
             const int64_t nt = ceil_div64(M_out, 64);
             k_conv128<64, 1, 4><<<dim3((unsigned)(ceil_div64(nt, 8) * 8)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, dbg_xcd);
         } else {
