@@ -732,7 +732,7 @@ DD3D_API int dd3d_conv_fwd(const float* X, int64_t M_in, int Cin, const float* W
         k_conv3_fwd<<<dim3((unsigned)(tiles < 512 ? tiles : 512)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, Y);
     } else {
         static const int dbg_tile = getenv("DD3D_CONV_TILE") ? atoi(getenv("DD3D_CONV_TILE")) : 0;
-        static const int dbg_xcd = getenv("DD3D_CONV_XCD") ? atoi(getenv("DD3D_CONV_XCD")) : 0;
+        static const int dbg_xcd = getenv("DD3D_CONV_XCD") ? atoi(getenv("DD3D_CONV_XCD")) : 1;  // XCD-aware tile order: same time, 10-50 % less L2 fill traffic (profiles/r01_pmc_conv128_rows.json)
         static const int dbg_rows = getenv("DD3D_CONV_ROWS") ? atoi(getenv("DD3D_CONV_ROWS")) : 1;
         const bool big = dbg_tile ? dbg_tile == 128 : M_out >= 128 * 512;
         if (big && dbg_rows) {
