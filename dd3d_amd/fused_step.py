@@ -25,7 +25,7 @@ import torch
 
 from . import _lib as L
 from .distillation_loss import _METRICS, _rows_cols
-from .ops import DensePlacement, _site_strides, sl_bwd_x_call, sl_fwd_call, transposed_kernel
+from .ops import DensePlacement, _site_strides, site_major, sl_bwd_x_call, sl_fwd_call, transposed_kernel
 from .sparse import CloudCoordinateManager, CoordinateManager
 from .utils.Mnist2D import batch_from_images
 
@@ -45,7 +45,8 @@ class _Pass:
     synthetic clouds come first, their points, voxel rows (at every stride) and clouds are PREFIXES of the arrays: the second-order
     pass is the same kernels called on the first ``B_syn`` clouds with the prefix's row counts (``seg_off[B_syn]``, on the device)."""
 
-    def __init__(self, net, coords, B, G, cloud_group, group_cloud_off, B_syn, N_syn, side, n_dev=None, static=False, pt_off=None, max_points=0):
+    def __init__(self, net, coords, B, G, cloud_group, group_cloud_off, B_syn, N_syn, side, n_dev=None, static=False, pt_off=None, max_points=0,
+                 extent=None):
         """Phase 1 (no host sync): every coordinate map, enqueued on the current stream.
         ``static``: never read a size back -- every launch covers its bound and takes the true row count from the device
         (``n_dev`` = number of valid rows of ``coords``), so the pass can be captured into a HIP graph."""
@@ -54,9 +55,11 @@ class _Pass:
         self.B_syn, self.N_syn, self.Gs = B_syn, N_syn, G // 2
         self.cloud_group, self.gco = cloud_group, group_cloud_off
         self.static, self.side = static, side
+        # dense() placement over `extent` sites per axis: the network's dense extent, or the (smaller) box the voxels can actually reach
+        self.extent = extent = tuple(net.dense_extent) if extent is None else tuple(extent)
         if pt_off is not None and 0 < max_points <= int(L.lib.dd3d_cloud_maps_max_points()):
             # clouds small enough for LDS: the whole pyramid (+ dense placement) in three launches
-            cm = CloudCoordinateManager(coords, pt_off, B, max_points, net.dense_extent, cloud_group, G, group_cloud_off)
+            cm = CloudCoordinateManager(coords, pt_off, B, max_points, extent, cloud_group, G, group_cloud_off)
         else:
             cm = CoordinateManager(coords, B, n_dev=n_dev)
         self.cm = cm
@@ -64,7 +67,7 @@ class _Pass:
         k0, p0 = cm.kernel_map(1, 1, 3), cm.kernel_map(1, 2, 2)
         k1, p1 = cm.kernel_map(2, 2, 3), cm.kernel_map(2, 4, 2)
         seg1, seg2 = cm.seg_off(1), cm.seg_off(2)
-        self.dp = DensePlacement(cm, 4, net.dense_extent, cloud_group, G, group_cloud_off)
+        self.dp = DensePlacement(cm, 4, extent, cloud_group, G, group_cloud_off)
         if getattr(cm, "group_row_off", None) is not None:
             gro1, gro2 = cm.group_row_off[0], cm.group_row_off[1]
         else:
@@ -95,8 +98,7 @@ class _Pass:
         J = cls_w.shape[0]
         S = dp.S
         self.J, self.S = J, S
-        from .ops import site_major
-        Wsm = self.Wsm = site_major(cls_w, 128, S)
+        Wsm = self.Wsm = compact_site_major(cls_w, 128, net.dense_extent, self.extent)
         sst = _site_strides(J, 128, S)
         W1t = self.W1t = transposed_kernel(conv1.kernel)
         self.params = (W0, W1, w1, b1, w5, b5)
@@ -235,6 +237,59 @@ def grouped_match_loss(gw_syn: List[torch.Tensor], gw_real: List[torch.Tensor], 
     return loss, dsyn
 
 
+def reachable_sites(full, compact):
+    """Flat indices (in the network's dense extent ``full``) of the sites of the corner box ``compact``, in the box's own row-major order."""
+    a, d, e = (torch.arange(n) for n in compact)
+    return ((a[:, None, None] * full[1] + d[None, :, None]) * full[2] + e[None, None, :]).reshape(-1)
+
+
+def compact_site_major(cls_w: torch.Tensor, C: int, full, compact) -> torch.Tensor:
+    """Site-major classifier operand [Sc, J, C] over the reachable sites only.  ``dense()`` places a voxel at (coordinate - batch minimum)
+    / 4 inside a [E0,E1,E2] box (MEConv.py:250-254); clouds clamped to [0, 27] reach 7 x 7 of the 28 x 28 sites, so 94 % of the
+    100 352 classifier columns only ever meet zeros.  Cached on the (frozen) weight, per box."""
+    full, compact = tuple(full), tuple(compact)
+    if compact == full:
+        return site_major(cls_w, C, full[0] * full[1] * full[2])
+    hit = getattr(cls_w, "_dd3d_csm", None)
+    if hit is not None and hit[0] == (cls_w._version, compact) and hit[1].device == cls_w.device:
+        return hit[1]
+    J = cls_w.shape[0]
+    idx = reachable_sites(full, compact).to(cls_w.device)
+    wc = cls_w.detach().reshape(J, C, -1)[:, :, idx].reshape(J, -1).contiguous()
+    out = site_major(wc, C, idx.numel())
+    try:
+        cls_w._dd3d_csm = ((cls_w._version, compact), out)
+    except Exception:
+        pass
+    return out
+
+
+class _GradList(list):
+    """Per-parameter gradient list [G, *shape] whose classifier-weight entry is held over the reachable sites only; indexing it
+    returns the parameter-shaped tensor (zeros elsewhere), expanded on first use.  The step itself never expands it."""
+
+    def __init__(self, tensors, full, compact, C=128):
+        super().__init__(tensors)
+        self._full, self._compact, self._C, self._done = tuple(full), tuple(compact), C, tuple(full) == tuple(compact)
+
+    def compact(self, i):
+        return list.__getitem__(self, i)
+
+    def __getitem__(self, i):
+        if i in (6, -2) and not self._done:
+            t = list.__getitem__(self, 6)
+            G, J = t.shape[0], t.shape[1]
+            S = self._full[0] * self._full[1] * self._full[2]
+            out = torch.zeros((G, J, self._C, S), dtype=t.dtype, device=t.device)
+            out[..., reachable_sites(self._full, self._compact).to(t.device)] = t.reshape(G, J, self._C, -1)
+            list.__setitem__(self, 6, out.reshape(G, J, self._C * S))
+            self._done = True
+        return list.__getitem__(self, i)
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
 class FusedDistiller:
     """Same constructor and state as ``mnist_distill.Distiller`` (MEConvExp only); ``outer_step`` runs the class-batched path.
 
@@ -287,6 +342,40 @@ class FusedDistiller:
         self.use_graph = bool(graph) and G > 0
         self._graph = self._static = None
         self._scope = "graph%x" % id(self)
+
+    def _real_range(self):
+        """(lo[3], hi[3]) of the real points before quantisation (one read-back, cached)."""
+        if getattr(self, "_rrange", None) is None:
+            if self.images_all is not None:
+                H, W = int(self.images_all.shape[-2]), int(self.images_all.shape[-1])
+                self._rrange = ([0.0, 0.0, 0.0], [0.0, H - 1.0, W - 1.0])   # Mnist2Dreal: points (0, y, x) of the on-pixels
+            else:
+                xyz = self._point_pool()[0]
+                self._rrange = (xyz.min(0).values.tolist(), xyz.max(0).values.tolist())
+        return self._rrange
+
+    def site_extent(self, real_batch=None):
+        """Sites per axis that a stride-4 voxel of this job can reach inside the network's dense extent: index = (coordinate - batch
+        minimum) / 4 <= floor(hi / 4) - floor(lo / 4) with [lo, hi] the floored coordinate range of the clamped synthetic points and
+        of the real data.  Without a clamp the full extent is kept."""
+        E = tuple(self.network.dense_extent)
+        if self.clamp_range is None:
+            return E
+        q = np.float32(self.quant)
+        slo, shi = [self.clamp_range[0]] * 3, [self.clamp_range[1]] * 3
+        if self.zero_first_axis:
+            slo[0] = shi[0] = 0.0
+        if real_batch is not None:   # an explicit batch brings its own (already quantised) coordinates
+            c = real_batch["coordinates"][:, 1:]
+            rlo, rhi = (np.floor(v) for v in (c.min(0).values.cpu().numpy(), c.max(0).values.cpu().numpy())) if c.shape[0] else ([0] * 3, [0] * 3)
+        else:
+            rlo, rhi = (np.floor(np.float32(v) / q) for v in (np.float32(self._real_range()[0]), np.float32(self._real_range()[1])))
+        out = []
+        for a in range(3):
+            lo = min(int(np.floor(np.float32(slo[a]) / q)), int(rlo[a]))
+            hi = max(int(np.floor(np.float32(shi[a]) / q)), int(rhi[a]))
+            out.append(max(1, min(E[a], hi // 4 - lo // 4 + 1)))
+        return tuple(out)
 
     def __del__(self):
         try:
@@ -416,19 +505,19 @@ class FusedDistiller:
                 "labels": torch.cat([self.syn_labels, rb["labels"].to(_I32)]), "num_clouds": Bs + int(rb["num_clouds"]),
                 "cloud_group": torch.cat([self.syn_group, rb["cloud_group"] + G]),
                 "group_cloud_off": torch.cat([self.syn_gco, rb["group_cloud_off"][1:] + Bs]),
-                "pt_off": torch.cat([self.syn_pt_off, pt[1:] + Ns]), "n_dev": None}
+                "pt_off": torch.cat([self.syn_pt_off, pt[1:] + Ns]), "n_dev": None, "extent": rb.get("extent")}
 
     def _compute(self, mb, static):
         """Everything after the merged batch ``mb`` exists: one forward / first-order backward over synthetic + real clouds, the matching
         loss, the second-order backward into the synthetic points, the SGD update."""
         dev, G, ipc, npts = self.device, self.G, self.ipc, self.num_points
         # cached layouts of the frozen weights are (re)built here if a weight changed
-        from .ops import site_major
         net = self.network
-        site_major(net.classifier.weight, 128, net.dense_extent[0] * net.dense_extent[1] * net.dense_extent[2])
+        extent = mb.get("extent") or self.site_extent()
+        compact_site_major(net.classifier.weight, 128, net.dense_extent, extent)
         transposed_kernel(net.features[4].kernel)
         p = _Pass(net, mb["coordinates"], int(mb["num_clouds"]), 2 * G, mb["cloud_group"], mb["group_cloud_off"], G * ipc, G * ipc * npts,
-                  self.stream_side, mb.get("n_dev"), static, mb.get("pt_off"), npts)
+                  self.stream_side, mb.get("n_dev"), static, mb.get("pt_off"), npts, extent)
         p.run(mb["features"], mb["labels"])
         gw_syn, gw_real = [t[:G] for t in p.gw], [t[G:] for t in p.gw]
         # only these entries of gw_syn depend on the synthetic points (SURVEY.md section 3.2): IN weights, classifier weight and bias
@@ -438,7 +527,8 @@ class FusedDistiller:
         grad = torch.zeros_like(self.image_syn)
         grad[self.syn_rows] = dfeats.reshape(G * ipc, npts, 3)
         Bs = G * ipc
-        self.last = {"per_class": loss_g, "grad": grad, "gw_real": gw_real, "gw_syn": gw_syn, "logits": (p.logits[Bs:], p.logits[:Bs]),
+        self.last = {"per_class": loss_g, "grad": grad, "gw_real": _GradList(gw_real, net.dense_extent, extent),
+                     "gw_syn": _GradList(gw_syn, net.dense_extent, extent), "logits": (p.logits[Bs:], p.logits[:Bs]),
                      "conv1_maps": [(p.maps[4], p.M[1], p.cnt[1])], "passes": (p,)}
         if self._apply_update:
             # momentum_buf starts at zero, so the first step needs no special case (0.5 * 0 + g == g exactly)
@@ -498,7 +588,8 @@ class FusedDistiller:
         self.clamp()
         main = torch.cuda.current_stream(self.device)
         if real_batch is not None:
-            rb = real_batch
+            rb = dict(real_batch)
+            rb["extent"] = self.site_extent(real_batch)
         elif self._prefetched is not None:
             rb, self._prefetched = self._prefetched, None
             main.wait_stream(self.stream_data)
