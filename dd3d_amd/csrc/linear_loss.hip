@@ -442,6 +442,57 @@ __global__ void k_sgd_clamp(float* __restrict__ x, const float* __restrict__ gra
     x[i] = v;
 }
 
+// Prologue of an iteration in ONE launch (mnist_distill.py:311-317 + get_syn_tensor :241-244 + create_input_batch MEConv.py:260-267):
+// clamp every synthetic point in place ([lo, hi], first axis := 0; comparisons, so a NaN stays a NaN as with the reference's masked
+// assignments), and write the points of the clouds this process owns into the head of the merged batch: coordinates (columns 1..3 of
+// [.,4] rows; column 0, the batch index, is constant and written once by the caller) = xyz / quantization_size, features = xyz.
+// dest_cloud[c] = position of cloud c among the owned clouds, or -1.
+__global__ void k_syn_head(float* __restrict__ xyz, int64_t n_points, int npts, const int* __restrict__ dest_cloud, int do_clamp, float lo, float hi,
+                           int zero_first, float quant, float* __restrict__ coords, float* __restrict__ feats) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_points) return;
+    float v[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float x = xyz[p * 3 + a];
+        if (do_clamp) {
+            x = x < lo ? lo : x;
+            x = x > hi ? hi : x;
+        }
+        if (zero_first && a == 0) x = 0.f;
+        v[a] = x;
+        xyz[p * 3 + a] = x;
+    }
+    const int64_t c = p / npts;
+    const int d = dest_cloud ? dest_cloud[c] : (int)c;
+    if (d < 0) return;
+    const int64_t r = (int64_t)d * npts + (p - c * npts);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        coords[r * 4 + 1 + a] = v[a] / quant;
+        feats[r * 3 + a] = v[a];
+    }
+}
+
+// Epilogue of an iteration in ONE launch: scatter the gradient of the owned clouds into the full-size gradient (zero elsewhere) and
+// take the SGD-with-momentum step (optimizer_img.step(), mnist_distill.py:369); same arithmetic as k_sgd_clamp.
+__global__ void k_sgd_scatter(float* __restrict__ x, float* __restrict__ mom, const float* __restrict__ dfeats, const int* __restrict__ dest_cloud,
+                              int64_t n_points, int npts, float lr, float momentum, float* __restrict__ grad_out) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_points) return;
+    const int64_t c = p / npts;
+    const int d = dest_cloud ? dest_cloud[c] : (int)c;
+    const int64_t r = (int64_t)d * npts + (p - c * npts);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float g = d >= 0 ? dfeats[r * 3 + a] : 0.f;
+        if (grad_out) grad_out[p * 3 + a] = g;
+        const float m = momentum * mom[p * 3 + a] + g;
+        mom[p * 3 + a] = m;
+        x[p * 3 + a] = x[p * 3 + a] - lr * m;
+    }
+}
+
 int build_plan(const dd3d_gseg* segs, int n, int metric, GPlan* p) {
     if (n <= 0 || n > DD3D_MAX_SEG || metric < 0 || metric > 3 || !segs) return DD3D_EARG;
     p->n = n;
@@ -601,6 +652,29 @@ DD3D_API int dd3d_sgd_momentum_clamp(float* x, const float* grad, float* mom, in
     if (n == 0) return 0;
     if (!x || !grad || !mom) return DD3D_EARG;
     k_sgd_clamp<<<dim3((unsigned)ceil_div64(n, 256)), 256, 0, (hipStream_t)stream>>>(x, grad, mom, n, lr, momentum, first_step, do_clamp, lo, hi);
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}
+
+DD3D_API int dd3d_syn_head(float* xyz, int64_t n_clouds, int npts, const int32_t* dest_cloud, int do_clamp, float lo, float hi, int zero_first,
+                           float quant, float* coords, float* feats, void* stream) {
+    if (n_clouds < 0 || npts <= 0 || quant == 0.f) return DD3D_EARG;
+    const int64_t n = n_clouds * npts;
+    if (n == 0) return 0;
+    if (!xyz || !coords || !feats) return DD3D_EARG;
+    k_syn_head<<<dim3((unsigned)ceil_div64(n, 256)), 256, 0, (hipStream_t)stream>>>(xyz, n, npts, dest_cloud, do_clamp, lo, hi, zero_first, quant, coords,
+                                                                                    feats);
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}
+
+DD3D_API int dd3d_sgd_scatter(float* xyz, float* mom, const float* dfeats, const int32_t* dest_cloud, int64_t n_clouds, int npts, float lr,
+                              float momentum, float* grad_out, void* stream) {
+    if (n_clouds < 0 || npts <= 0) return DD3D_EARG;
+    const int64_t n = n_clouds * npts;
+    if (n == 0) return 0;
+    if (!xyz || !mom || !dfeats) return DD3D_EARG;
+    k_sgd_scatter<<<dim3((unsigned)ceil_div64(n, 256)), 256, 0, (hipStream_t)stream>>>(xyz, mom, dfeats, dest_cloud, n, npts, lr, momentum, grad_out);
     DD3D_CHECK_LAUNCH();
     return 0;
 }

@@ -330,6 +330,9 @@ class FusedDistiller:
         cls = torch.tensor(self.classes, device=dev)
         # rows of image_syn owned by this process, class-major
         self.syn_rows = (cls[:, None] * ipc + torch.arange(ipc, device=dev)[None, :]).reshape(-1)
+        # position of every synthetic cloud among the owned ones (-1: another rank's), for the one-launch prologue / epilogue
+        self.dest_cloud = torch.full((num_classes * ipc,), -1, dtype=_I32, device=dev)
+        self.dest_cloud[self.syn_rows] = torch.arange(G * ipc, dtype=_I32, device=dev)
         self.syn_labels = cls.repeat_interleave(ipc).to(_I32)
         self.syn_group = torch.arange(G, device=dev, dtype=_I32).repeat_interleave(ipc)
         self.syn_gco = (torch.arange(G + 1, device=dev) * ipc).to(_I32)
@@ -524,14 +527,20 @@ class FusedDistiller:
         need = [False, True, False, False, True, False, True, True]
         loss_g, d = grouped_match_loss(gw_syn, gw_real, self.dist_opt, G, need)
         dfeats = p.backward_to_points(d[1], d[4], d[6], d[7], ipc)
-        grad = torch.zeros_like(self.image_syn)
-        grad[self.syn_rows] = dfeats.reshape(G * ipc, npts, 3)
+        grad = torch.empty_like(self.image_syn)
+        fused_tail = self._apply_update and self.image_syn.shape[1] == npts
+        if not fused_tail:
+            grad.zero_()
+            grad[self.syn_rows] = dfeats.reshape(G * ipc, npts, 3)
         Bs = G * ipc
         self.last = {"per_class": loss_g, "grad": grad, "gw_real": _GradList(gw_real, net.dense_extent, extent),
                      "gw_syn": _GradList(gw_syn, net.dense_extent, extent), "logits": (p.logits[Bs:], p.logits[:Bs]),
                      "conv1_maps": [(p.maps[4], p.M[1], p.cnt[1])], "passes": (p,)}
-        if self._apply_update:
-            # momentum_buf starts at zero, so the first step needs no special case (0.5 * 0 + g == g exactly)
+        if fused_tail:
+            # gradient scatter + SGD in one launch; momentum_buf starts at zero, so the first step needs no special case (0.5 * 0 + g == g)
+            L.call("dd3d_sgd_scatter", L.ptr(self.image_syn), L.ptr(self.momentum_buf), L.ptr(dfeats), L.ptr(self.dest_cloud),
+                   self.image_syn.shape[0], npts, self.lr, self.momentum, L.ptr(grad), L.stream())
+        elif self._apply_update:
             L.call("dd3d_sgd_momentum_clamp", L.ptr(self.image_syn), L.ptr(grad), L.ptr(self.momentum_buf), self.image_syn.numel(), self.lr,
                    self.momentum, 0, 0, 0.0, 27.0, L.stream())
         return loss_g.sum()
@@ -539,11 +548,13 @@ class FusedDistiller:
     def _static_body(self):
         """clamp + on-device batch assembly + the step, all on fixed addresses with device-side sizes (what the graph captures)."""
         st = self._static
-        self.clamp()
         Bs, Ns = self.G * self.ipc, self.G * self.ipc * self.num_points
-        xyz = self.image_syn[self.syn_rows].reshape(-1, 3)           # coordinates and features of a synthetic point are the same tensor
-        st.coords[:Ns, 1:] = xyz / self.quant if self.quant != 1.0 else xyz   # create_input_batch: coordinates / quantization_size
-        st.feats[:Ns] = xyz
+        # clamp + the owned synthetic clouds into the head of the merged batch (coordinates = xyz / quantization_size, features = xyz:
+        # the same tensor twice, Mnist2D.py:84-92), one launch
+        cr = self.clamp_range
+        L.call("dd3d_syn_head", L.ptr(self.image_syn), self.image_syn.shape[0], self.num_points, L.ptr(self.dest_cloud), int(cr is not None),
+               float(cr[0]) if cr else 0.0, float(cr[1]) if cr else 0.0, int(self.zero_first_axis), self.quant, L.ptr(st.coords), L.ptr(st.feats),
+               L.stream())
         L.call("dd3d_gather_clouds", L.ptr(st.pool_xyz), L.ptr(st.pool_off), st.n_pool, L.ptr(st.ids), st.B, self.num_points, st.bound_total,
                Bs, Ns, self.quant, L.ptr(st.coords), L.ptr(st.feats), L.ptr(st.pt_off), L.ptr(st.n), L.ptr(st.err), L.stream())
         mb = {"coordinates": st.coords, "features": st.feats, "labels": st.labels, "num_clouds": Bs + st.B, "cloud_group": st.cloud_group,

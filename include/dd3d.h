@@ -235,6 +235,18 @@ int dd3d_match_loss_bwd(const dd3d_gseg* segs, int n, int G, int metric, const f
 int dd3d_sgd_momentum_clamp(float* x, const float* grad, float* mom, int64_t n, float lr, float momentum, int first_step, int do_clamp, float lo,
                             float hi, void* stream);
 
+/* Prologue of an iteration in one launch: clamp all synthetic points in place (do_clamp: [lo,hi]; zero_first: first axis := 0) and write
+ * the clouds this process owns (dest_cloud[c] = position among the owned clouds or -1; NULL = all, in order) into the head of the
+ * merged batch: coords[r][1..3] = xyz / quant ([.,4] rows, column 0 untouched), feats[r] = xyz.
+ * replaces: the clamp mnist_distill.py:311-317, get_syn_tensor :241-244, Mnist2Dsyn.__getitem__ Mnist2D.py:84-92, create_input_batch MEConv.py:260-267 */
+int dd3d_syn_head(float* xyz, int64_t n_clouds, int npts, const int32_t* dest_cloud, int do_clamp, float lo, float hi, int zero_first,
+                  float quant, float* coords, float* feats, void* stream);
+
+/* Epilogue in one launch: grad_out (nullable, full size) = the owned clouds' gradient dfeats scattered back, zero elsewhere;
+ * mom = momentum*mom + grad; xyz -= lr*mom.  replaces: image_syn.grad assembly + optimizer_img.step(), mnist_distill.py:365,369 */
+int dd3d_sgd_scatter(float* xyz, float* mom, const float* dfeats, const int32_t* dest_cloud, int64_t n_clouds, int npts, float lr,
+                     float momentum, float* grad_out, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------------
  * (6) evaluation block: synthetic clouds -> occupancy images
  * ------------------------------------------------------------------------------------------------------------------- */
