@@ -19,49 +19,60 @@ struct WStride {
 };
 
 // Forward in two short launches instead of one long per-cloud loop (a cloud's voxels were walked serially, one dependent
-// site -> weight-row round trip each): (1) one WAVE per voxel -- its 128 features sit in the wave (float2 per lane) and are
-// multiplied into the J outputs' 512-B weight rows, 64-lane reductions give part[v][j]; (2) one thread per (cloud, output) adds the
-// cloud's voxels in row order (+ bias): deterministic.
+// site -> weight-row round trip each): (1) SIXTEEN lanes per voxel (four voxels per wave) -- a lane holds 8 of the voxel's 128 features
+// and multiplies them into its 32-B piece of each output's 512-B weight row; the 16 partial sums meet in four DPP adds (no LDS
+// traffic), part[v][j]; (2) one thread per (cloud, output) adds the cloud's voxels in row order (+ bias): deterministic.
+__device__ __forceinline__ float row16_sum(float v) {
+    // sum over the 16 lanes of a DPP row; every lane ends with the total
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+    return v;
+}
+
 __global__ __launch_bounds__(256) void k_sl_fwd_part(const float* __restrict__ F, const int* __restrict__ site, const int4* __restrict__ coords,
                                                      const int* __restrict__ m_ptr, const int* __restrict__ cloud_group, const float* __restrict__ Wl,
                                                      WStride ws, int J, float* __restrict__ part) {
-    const int lane = threadIdx.x & 63;
+    const int l16 = threadIdx.x & 15;
     const int M = *m_ptr;
-    // grid-stride over the voxels: the launch is sized for the chip, not for the bound (a bound-sized grid of 4-voxel workgroups
-    // would spend its time dispatching empty workgroups)
-    for (int v = blockIdx.x * 4 + (threadIdx.x >> 6); v < M; v += gridDim.x * 4) {
-    const int s = site[v];
-    float* out = part + (int64_t)v * J;
-    if (s < 0) {
-        if (lane < J) out[lane] = 0.f;
-        for (int j = 64 + lane; j < J; j += 64) out[j] = 0.f;
-        continue;
-    }
-    const int g = cloud_group ? cloud_group[coords[v].x] : 0;
-    const float2 f = *(const float2*)(F + (int64_t)v * 128 + lane * 2);
-    const float* Ws = Wl + g * ws.g + s * ws.s;
     const bool unit_c = ws.c == 1;
-    for (int j0 = 0; j0 < J; j0 += 16) {
-        float acc[16];
+    // grid-stride over the voxels: the launch is sized for the chip, not for the bound (a bound-sized grid of small workgroups
+    // would spend its time dispatching empty workgroups).  The trip count is uniform over a wave (the DPP adds need all 16 lanes of a row).
+    for (int v0 = blockIdx.x * 16; v0 < M; v0 += gridDim.x * 16) {
+        const int v = v0 + (threadIdx.x >> 4);
+        const bool live = v < M;
+        const int vc = live ? v : M - 1;
+        const int s = site[vc];
+        const int g = cloud_group ? cloud_group[coords[vc].x] : 0;
+        const f32x4* Fv = (const f32x4*)(F + (int64_t)vc * 128 + l16 * 8);
+        const f32x4 f0 = Fv[0], f1 = Fv[1];
+        const float* Ws = Wl + g * ws.g + (int64_t)max(s, 0) * ws.s;
+        float* out = part + (int64_t)vc * J;
+        for (int j0 = 0; j0 < J; j0 += 10) {
+            float acc[10];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int j = min(j0 + u, J - 1);  // clamped: all 16 weight rows are loaded without a branch, extras are dropped below
-            const float* Wj = Ws + (int64_t)j * ws.j;
-            float w0, w1;
-            if (unit_c) {
-                const float2 w = *(const float2*)(Wj + lane * 2);
-                w0 = w.x; w1 = w.y;
-            } else {
-                w0 = Wj[(int64_t)(lane * 2) * ws.c]; w1 = Wj[(int64_t)(lane * 2 + 1) * ws.c];
+            for (int u = 0; u < 10; ++u) {
+                const float* Wj = Ws + (int64_t)min(j0 + u, J - 1) * ws.j;  // clamped: the weight rows are loaded without a branch
+                f32x4 w0, w1;
+                if (unit_c) {
+                    w0 = *(const f32x4*)(Wj + l16 * 8);
+                    w1 = *(const f32x4*)(Wj + l16 * 8 + 4);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        w0[e] = Wj[(int64_t)(l16 * 8 + e) * ws.c];
+                        w1[e] = Wj[(int64_t)(l16 * 8 + 4 + e) * ws.c];
+                    }
+                }
+                acc[u] = f0[0] * w0[0] + f0[1] * w0[1] + f0[2] * w0[2] + f0[3] * w0[3] + f1[0] * w1[0] + f1[1] * w1[1] + f1[2] * w1[2] + f1[3] * w1[3];
             }
-            acc[u] = f.x * w0 + f.y * w1;
-        }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const float t = wave_sum(acc[u]);
-            if (lane == u && j0 + u < J) out[j0 + u] = t;
+            for (int u = 0; u < 10; ++u) {
+                const float t = row16_sum(acc[u]);
+                if (live && l16 == u && j0 + u < J) out[j0 + u] = s < 0 ? 0.f : t;
+            }
         }
-    }
     }
 }
 
@@ -75,31 +86,41 @@ __global__ void k_sl_fwd_sum(const float* __restrict__ part, const int* __restri
     out[t] = bias ? s + bias[j] : s;
 }
 
-// dF[v][c] = sum_j dl[b(v)][j] * Wl[g][j][c][s(v)]: every voxel is independent -> grid over voxels (2 per workgroup, 128 channel lanes)
+// dF[v][c] = sum_j dl[b(v)][j] * Wl[g][j][c][s(v)]: every voxel is independent -> grid over voxels (8 per workgroup, 32 float4 channel
+// lanes each: with a site-major operand a lane reads one 16-B piece of each output's weight row)
 __global__ __launch_bounds__(256) void k_sl_bwd_x(const float* __restrict__ dl, const int* __restrict__ site, const int4* __restrict__ coords,
                                                   const int* __restrict__ m_ptr, const int* __restrict__ cloud_group, const float* __restrict__ Wl,
                                                   WStride ws, int J, int accumulate, float* __restrict__ dF) {
-    const int c = threadIdx.x & 127;
+    const int c4 = threadIdx.x & 31;
     const int M = *m_ptr;
-    for (int v = blockIdx.x * 2 + (threadIdx.x >> 7); v < M; v += gridDim.x * 2) {  // grid-stride: see k_sl_fwd_part
-    const int s = site[v];
-    const int b = coords[v].x;
-    const int g = cloud_group ? cloud_group[b] : 0;
-    float acc = 0.f;
-    if (s >= 0) {
-        const float* Wg = Wl + g * ws.g + c * ws.c + s * ws.s;
-        const float* d = dl + (int64_t)b * J;
-        for (int j0 = 0; j0 < J; j0 += 16) {
-            float w[16];
+    const bool unit_c = ws.c == 1;
+    for (int v = blockIdx.x * 8 + (threadIdx.x >> 5); v < M; v += gridDim.x * 8) {  // grid-stride: see k_sl_fwd_part
+        const int s = site[v];
+        const int b = coords[v].x;
+        const int g = cloud_group ? cloud_group[b] : 0;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (s >= 0) {
+            const float* Wg = Wl + g * ws.g + (int64_t)(c4 * 4) * ws.c + s * ws.s;
+            const float* d = dl + (int64_t)b * J;
+            for (int j0 = 0; j0 < J; j0 += 10) {
+                f32x4 w[10];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) w[u] = Wg[(int64_t)min(j0 + u, J - 1) * ws.j];
+                for (int u = 0; u < 10; ++u) {
+                    const float* Wj = Wg + (int64_t)min(j0 + u, J - 1) * ws.j;
+                    if (unit_c) {
+                        w[u] = *(const f32x4*)Wj;
+                    } else {
 #pragma unroll
-            for (int u = 0; u < 16; ++u)
-                if (j0 + u < J) acc += d[j0 + u] * w[u];
+                        for (int e = 0; e < 4; ++e) w[u][e] = Wj[(int64_t)e * ws.c];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 10; ++u)
+                    if (j0 + u < J) acc += d[j0 + u] * w[u];
+            }
         }
-    }
-    const int64_t o = (int64_t)v * 128 + c;
-    dF[o] = accumulate ? dF[o] + acc : acc;
+        f32x4* o = (f32x4*)(dF + (int64_t)v * 128) + c4;
+        *o = accumulate ? *o + acc : acc;
     }
 }
 
@@ -120,14 +141,21 @@ __global__ __launch_bounds__(256) void k_sl_bwd_w(const float* __restrict__ dl, 
         f32x4 acc[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int b = b0 + bl; b < b1; b += 8) {
-            int v = va[b];
-            if (v < 0) continue;
-            f32x4 f = F4[(int64_t)v * 32 + c4];
-            const float* d = dl + (int64_t)b * J + j0;
+        for (int bb = b0 + bl; bb < b1; bb += 32) {  // four clouds of this lane at a time: their table reads, then their row gathers, overlap
+            int vv[4];
+            f32x4 ff[4];
 #pragma unroll
-            for (int u = 0; u < 16; ++u)
-                if (j0 + u < J) acc[u] += d[u] * f;
+            for (int q = 0; q < 4; ++q) vv[q] = bb + 8 * q < b1 ? va[bb + 8 * q] : -1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ff[q] = F4[(int64_t)max(vv[q], 0) * 32 + c4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (vv[q] < 0) continue;  // same clouds in the same order as a one-by-one walk
+                const float* d = dl + (int64_t)(bb + 8 * q) * J + j0;
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (j0 + u < J) acc[u] += d[u] * ff[q];
+            }
         }
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
@@ -536,7 +564,7 @@ DD3D_API int dd3d_sparse_linear_fwd(const float* F, const int32_t* site, const i
     if (!ws || ws_bytes < dd3d_sparse_linear_ws_bytes(M_bound, J)) return DD3D_EWS;
     hipStream_t st = (hipStream_t)stream;
     if (M_bound > 0)
-        k_sl_fwd_part<<<dim3((unsigned)(ceil_div64(M_bound, 4) < 4096 ? ceil_div64(M_bound, 4) : 4096)), 256, 0, st>>>(F, site, (const int4*)coords, seg_off + B, cloud_group, Wl, mk_stride(strides),
+        k_sl_fwd_part<<<dim3((unsigned)(ceil_div64(M_bound, 16) < 2048 ? ceil_div64(M_bound, 16) : 2048)), 256, 0, st>>>(F, site, (const int4*)coords, seg_off + B, cloud_group, Wl, mk_stride(strides),
                                                                              J, (float*)ws);
     k_sl_fwd_sum<<<dim3((unsigned)ceil_div64((int64_t)B * J, 256)), 256, 0, st>>>((const float*)ws, seg_off, B, J, bias, out);
     DD3D_CHECK_LAUNCH();
@@ -549,7 +577,7 @@ DD3D_API int dd3d_sparse_linear_bwd_x(const float* dl, const int32_t* site, cons
     if (B < 0 || C != 128 || J <= 0 || M_bound < 0 || !strides) return DD3D_EARG;
     if (B == 0 || M_bound == 0) return 0;
     if (!dl || !site || !coords || !seg_off || !Wl || !dF) return DD3D_EARG;
-    k_sl_bwd_x<<<dim3((unsigned)(ceil_div64(M_bound, 2) < 8192 ? ceil_div64(M_bound, 2) : 8192)), 256, 0, (hipStream_t)stream>>>(dl, site, (const int4*)coords, seg_off + B, cloud_group, Wl,
+    k_sl_bwd_x<<<dim3((unsigned)(ceil_div64(M_bound, 8) < 4096 ? ceil_div64(M_bound, 8) : 4096)), 256, 0, (hipStream_t)stream>>>(dl, site, (const int4*)coords, seg_off + B, cloud_group, Wl,
                                                                                        mk_stride(strides), J, accumulate, dF);
     DD3D_CHECK_LAUNCH();
     return 0;
