@@ -30,6 +30,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---- device helpers -------------------------------------------------------------------------
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence + s_barrier, and the fence drains EVERY
+// counter (s_waitcnt vmcnt(0)): global stores issued before it and register prefetches in flight across it are waited for, which
+// serialises a tile loop on HBM latency.  Use this where the barrier protects nothing but LDS data.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 __device__ __forceinline__ uint32_t hash_coord(int4 c) {

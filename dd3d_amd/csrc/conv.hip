@@ -431,6 +431,7 @@ __global__ __launch_bounds__(256) void k_slab_reduce(const f32x4* __restrict__ s
 
 // ---------------------------------------------------------------------------------------------
 // Cin = 3, Cout = 128 (first layer): bandwidth kernels on the VALU
+struct __attribute__((packed, aligned(4))) f32x3 { float x, y, z; };
 // ---------------------------------------------------------------------------------------------
 // Y[o][:] = sum_k X[nbr[k][o]][0:3] . W[k][0:3][:] as a [64 x 96] x [96 x 128] product per tile on the fp32 matrix cores.  The
 // im2col tile A[o][3 pos(k) + ci] is gathered into LDS with coalesced neighbour-table reads (64 consecutive rows per offset); the
@@ -461,21 +462,32 @@ __global__ __launch_bounds__(256) void k_conv3_fwd(const float* __restrict__ X, 
     }
     for (int i = tid; i < 64 * LDA; i += 256) As[i] = 0.f;  // columns 81..96 stay zero
     const int sr = tid & 63, sk = tid >> 6;                 // staging: row of the tile, offset lane (4 lanes walk the 27 offsets)
-    for (int64_t row0 = (int64_t)blockIdx.x * 64; row0 < M_out; row0 += (int64_t)gridDim.x * 64) {  // persistent: tiles strided by the grid
-        if (tid == 0) s_pmask = 0;
-        __syncthreads();  // previous tile's MFMA reads of As are done; zero fill visible
-        unsigned mymask = 0;
-        const int64_t row = min(row0 + sr, (int64_t)M_out - 1);  // clamped: every load below has a valid address, no branches,
-        const bool live = row0 + sr < M_out;                     // so the 7 table loads and then the 7 gathers are all in flight
-        int nb[7];
+    // Two-stage software pipeline over the workgroup's tiles: while the matrix cores work on tile t, the gathers of tile t+1 (through the
+    // table entries read one iteration ago) and the table reads of tile t+2 are in flight; nothing is waited for in the iteration
+    // that issues it.
+    int nb[7], nb2[7];
+    float xv[7][3];
+    const int64_t tstep = (int64_t)gridDim.x * 64;
+    auto load_nb = [&](int64_t row0, int* dst) {  // clamped: every load has a valid address, no branches
+        const int64_t row = min(row0 + sr, (int64_t)M_out - 1);
 #pragma unroll
-        for (int kk = 0; kk < 7; ++kk) nb[kk] = nbr[(int64_t)min(sk + kk * 4, 26) * ld + row];
-        float xv[7][3];
+        for (int kk = 0; kk < 7; ++kk) dst[kk] = nbr[(int64_t)min(sk + kk * 4, 26) * ld + row];
+    };
+    auto gather = [&]() {
 #pragma unroll
         for (int kk = 0; kk < 7; ++kk) {
-            const float* x = X + (int64_t)max(nb[kk], 0) * 3;
-            xv[kk][0] = x[0]; xv[kk][1] = x[1]; xv[kk][2] = x[2];
+            const f32x3 x = *(const f32x3*)(X + (int64_t)max(nb[kk], 0) * 3);  // one 12-B load, not three dwords
+            xv[kk][0] = x.x; xv[kk][1] = x.y; xv[kk][2] = x.z;
         }
+    };
+    load_nb((int64_t)blockIdx.x * 64, nb);
+    load_nb((int64_t)blockIdx.x * 64 + tstep, nb2);
+    gather();
+    for (int64_t row0 = (int64_t)blockIdx.x * 64; row0 < M_out; row0 += tstep) {  // persistent: tiles strided by the grid
+        if (tid == 0) s_pmask = 0;
+        lds_barrier();  // previous tile's MFMA reads of As are done; zero fill visible.  LDS-only: the output stores stay in flight
+        unsigned mymask = 0;
+        const bool live = row0 + sr < M_out;
 #pragma unroll
         for (int kk = 0; kk < 7; ++kk) {
             const int k = sk + kk * 4;
@@ -489,7 +501,11 @@ __global__ __launch_bounds__(256) void k_conv3_fwd(const float* __restrict__ X, 
             }
         }
         if (mymask) atomicOr(&s_pmask, mymask);
-        __syncthreads();
+        lds_barrier();
+#pragma unroll
+        for (int kk = 0; kk < 7; ++kk) nb[kk] = nb2[kk];
+        gather();                          // tile t+1
+        load_nb(row0 + 2 * tstep, nb2);    // tile t+2
         const unsigned pmask = __builtin_amdgcn_readfirstlane(s_pmask);  // wave-uniform: chunk skipping is a scalar branch
         f32x16 acc[2];
 #pragma unroll
@@ -611,8 +627,8 @@ __global__ __launch_bounds__(256) void k_conv3_bww(const float* __restrict__ X, 
     auto load_x = [&](const int* nb, float (*xv)[3]) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            const float* x = X + (int64_t)max(nb[kk], 0) * 3;
-            xv[kk][0] = x[0]; xv[kk][1] = x[1]; xv[kk][2] = x[2];
+            const f32x3 x = *(const f32x3*)(X + (int64_t)max(nb[kk], 0) * 3);  // one 12-B load, not three dwords
+            xv[kk][0] = x.x; xv[kk][1] = x.y; xv[kk][2] = x.z;
         }
     };
     auto load_d = [&](int rb, f32x4* d) {
@@ -729,7 +745,8 @@ DD3D_API int dd3d_conv_fwd(const float* X, int64_t M_in, int Cin, const float* W
     if (Cin == 3) {
         if (mirror) return DD3D_EARG;
         const int64_t tiles = ceil_div64(M_out, 64);
-        k_conv3_fwd<<<dim3((unsigned)(tiles < 512 ? tiles : 512)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, Y);
+        static const int cap = getenv("DD3D_CONV3_WGS") ? atoi(getenv("DD3D_CONV3_WGS")) : 512;
+        k_conv3_fwd<<<dim3((unsigned)(tiles < cap ? tiles : cap)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, Y);
     } else {
         static const int dbg_tile = getenv("DD3D_CONV_TILE") ? atoi(getenv("DD3D_CONV_TILE")) : 0;
         static const int dbg_xcd = getenv("DD3D_CONV_XCD") ? atoi(getenv("DD3D_CONV_XCD")) : 1;  // XCD-aware tile order: same time, 10-50 % less L2 fill traffic (profiles/r01_pmc_conv128_rows.json)
