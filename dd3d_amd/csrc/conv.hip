@@ -177,25 +177,35 @@ __global__ __launch_bounds__(256) void k_conv128(const float* __restrict__ X, co
 // order of the accumulation are those of k_conv128, so the two kernels give bit-identical results.
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_conv128_rows(const float* __restrict__ X, const float* __restrict__ W, const int* __restrict__ nbr, int64_t ld,
-                                                          int K, int M_bound, const int* __restrict__ m_dev, int mirror, float* __restrict__ Y, int xcd_remap) {
+                                                          int K, int M_bound, const int* __restrict__ m_dev, int mirror, float* __restrict__ Y, int xcd_remap,
+                                                          const int* __restrict__ perm, const int* __restrict__ tile_map) {
     constexpr int TM = NW * 32, NTH = NW * 64, BPT = 1024 / NTH;
     __shared__ f32x4 Bs4[2][32 * 32];
     __shared__ int s_nbr[27 * TM];
+    __shared__ int s_row[TM];  // output row of each tile slot: row0 + r, or perm[row0 + r] (rows grouped by neighbour pattern, see k_row_order)
     __shared__ unsigned s_kmask;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int i32 = lane & 31, h = lane >> 5;
     const int M_out = m_dev ? min(*m_dev, M_bound) : M_bound;
     const int ntile = (M_out + TM - 1) / TM, per_xcd = (ntile + 7) / 8;
-    const int tile = xcd_remap ? (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    int tile = (xcd_remap && !tile_map) ? (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (tile_map) {  // scheduled launch (sched.hip): workgroup -> tile of the pattern-sorted row order, balanced over the CUs
+        tile = tile_map[blockIdx.x];
+        if (tile < 0) return;
+    }
     const int64_t row0 = (int64_t)tile * TM;
-    if (tile >= ntile || (xcd_remap && (int)(blockIdx.x >> 3) >= per_xcd)) return;
+    if (tile >= ntile || (!tile_map && xcd_remap && (int)(blockIdx.x >> 3) >= per_xcd)) return;
 
     if (tid == 0) s_kmask = 0;
+    if (tid < TM) {
+        const int64_t slot = row0 + tid;
+        s_row[tid] = slot < M_out ? (perm ? perm[slot] : (int)slot) : M_out;  // slots past the end (and rows a partial window maps past it) are dead
+    }
     __syncthreads();
     unsigned mymask = 0;
     for (int idx = tid; idx < K * TM; idx += NTH) {
         int k = idx / TM, r = idx - k * TM;
-        int64_t row = row0 + r;
+        const int row = s_row[r];
         int ks = mirror ? K - 1 - k : k;
         int v = row < M_out ? nbr[(int64_t)ks * ld + row] : -1;
         s_nbr[idx] = v;
@@ -276,7 +286,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv128_rows(const float* __restric
     f32x4* Y4 = (f32x4*)Y;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int64_t row = row0 + wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int64_t row = s_row[wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
         const f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
         if (row < M_out) Y4[row * 32 + i32] = v;
     }
@@ -754,7 +764,7 @@ DD3D_API int dd3d_conv_fwd(const float* X, int64_t M_in, int Cin, const float* W
         const bool big = dbg_tile ? dbg_tile == 128 : M_out >= 128 * 512;
         if (big && dbg_rows) {
             const int64_t nt = ceil_div64(M_out, 128);
-            k_conv128_rows<4><<<dim3((unsigned)(ceil_div64(nt, 8) * 8)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, dbg_xcd);
+            k_conv128_rows<4><<<dim3((unsigned)(ceil_div64(nt, 8) * 8)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, dbg_xcd, nullptr, nullptr);
         } else if (big) {
             const int64_t nt = ceil_div64(M_out, 128);
             k_conv128<128, 2, 2><<<dim3((unsigned)(ceil_div64(nt, 8) * 8)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, dbg_xcd);
@@ -767,6 +777,22 @@ DD3D_API int dd3d_conv_fwd(const float* X, int64_t M_in, int Cin, const float* W
             k_conv128<32, 1, 4><<<dim3((unsigned)(ceil_div64(nt, 8) * 8)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, dbg_xcd);
         }
     }
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}
+
+// dd3d_conv_fwd for Cin = Cout = 128 along a schedule of dd3d_conv_schedule (same nbr / M_out / m_dev): rows in the order of `perm`,
+// workgroup b on tile tile_map[b].  Same result as dd3d_conv_fwd, bit for bit; fewer all-zero rows through the matrix cores and an even
+// load over the CUs.
+DD3D_API int64_t dd3d_conv_schedule_blocks(int64_t M);
+DD3D_API int dd3d_conv128_ordered(const float* X, int64_t M_in, const float* W, const int32_t* nbr, int64_t ld, int K, int64_t M_out, const int32_t* m_dev,
+                                  int mirror, const int32_t* perm, const int32_t* tile_map, float* Y, void* stream) {
+    if (M_out < 0 || M_in < 0 || K != 27 || ld < M_out) return DD3D_EARG;
+    if (M_out >= (1ll << 31) / 128 * 16) return DD3D_ESIZE;
+    if (M_out == 0) return 0;
+    if (!X || !W || !nbr || !Y || !perm || !tile_map) return DD3D_EARG;
+    k_conv128_rows<4><<<dim3((unsigned)dd3d_conv_schedule_blocks(M_out)), 256, 0, (hipStream_t)stream>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, 0, perm,
+                                                                                                        tile_map);
     DD3D_CHECK_LAUNCH();
     return 0;
 }

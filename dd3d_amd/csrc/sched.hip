@@ -1,0 +1,204 @@
+// Launch schedule of the 128-channel sparse convolution (k_conv128_rows with `perm` and `tile_map`, conv.hip).
+//
+// The convolution is output-stationary: a 32-row block skips an offset only when NONE of its rows has that neighbour, and a 128-row
+// tile walks the union of its four blocks' offsets.  In cloud order stroke digits execute 1.37x the algorithmic MFMA work (73 % of the
+// 9 in-plane neighbours present).  Two steps remove most of that:
+//   1. row order: the rows are grouped by their K-bit neighbour pattern -- a counting sort over 4096 hash buckets of the pattern (rows
+//      with the same pattern share a bucket; which of them comes first inside a bucket is left to the atomics, see below): 1.04x the
+//      algorithmic work at 128-row granularity.  A row's sum does not depend on the rows it shares a block with (the skipped products
+//      are exact zeros), so the convolution's output is bit-identical for ANY order -- the order only decides how fast it runs.
+//   2. tile placement: a sorted launch has heavy tiles (all 9 offsets) and light ones, and a launch on an idle GPU puts workgroup b on
+//      CU b mod 256 with every workgroup resident at once (tools/place_probe), so it lasts as long as the most loaded CU.  The tiles
+//      are therefore ranked by their true cost (offsets in the tile's union) and dealt to the CUs in a snake -- round 0 forwards, round
+//      1 backwards, ... -- which is as even as greedy longest-processing-time assignment on these distributions (76 vs 108 steps on
+//      the most loaded CU for the cfg2 real batch).
+// One schedule serves the forward and the mirrored (backward-data) launch over the same kernel map: mirroring permutes the bits of every
+// pattern alike.
+#include "common.h"
+
+namespace {
+
+constexpr int NB = 4096;  // hash buckets of the neighbour pattern
+
+__device__ __forceinline__ unsigned row_pattern(const int* __restrict__ nbr, int64_t ld, int K, int row) {
+    unsigned key = 0;
+    for (int k = 0; k < K; ++k) key |= (unsigned)(nbr[(int64_t)k * ld + row] >= 0) << k;
+    return key;
+}
+__device__ __forceinline__ int pattern_bucket(unsigned key) { return (int)((key * 0x9E3779B1u) >> 20); }
+
+// keys[i] = pattern of row i; hist[b] += rows of bucket b (one LDS histogram per workgroup of 4096 rows, then one global add per bucket it met)
+__global__ __launch_bounds__(1024) void k_row_keys(const int* __restrict__ nbr, int64_t ld, int K, int M_bound, const int* __restrict__ m_dev,
+                                                   unsigned* __restrict__ keys, int* __restrict__ hist) {
+    __shared__ int s_h[NB];
+    const int M = m_dev ? min(*m_dev, M_bound) : M_bound;
+    const int i0 = blockIdx.x * 4096;
+    if (i0 >= M) return;
+    for (int b = threadIdx.x; b < NB; b += 1024) s_h[b] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = i0 + j * 1024 + threadIdx.x;
+        if (i < M) {
+            const unsigned key = row_pattern(nbr, ld, K, i);
+            keys[i] = key;
+            atomicAdd(&s_h[pattern_bucket(key)], 1);
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < NB; b += 1024)
+        if (s_h[b]) atomicAdd(&hist[b], s_h[b]);
+}
+
+// hist -> exclusive prefix, in place (it then serves as the buckets' write cursors)
+__global__ __launch_bounds__(1024) void k_bucket_scan(int* __restrict__ hist) {
+    __shared__ int s_w[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int v[4], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[j] = hist[tid * 4 + j];
+        sum += v[j];
+    }
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_w[w] = incl;
+    __syncthreads();
+    int base = incl - sum;
+    for (int q = 0; q < w; ++q) base += s_w[q];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        hist[tid * 4 + j] = base;
+        base += v[j];
+    }
+}
+
+// perm / sorted_keys: every workgroup reserves, per bucket, a run behind the bucket's cursor (one global atomic per bucket it holds) and
+// ranks its rows inside the run with LDS atomics.  The order inside a bucket therefore depends on the atomics' arrival; the
+// convolution's output does not (see the file comment).
+__global__ __launch_bounds__(1024) void k_row_scatter(const unsigned* __restrict__ keys, int M_bound, const int* __restrict__ m_dev, int* __restrict__ cursor,
+                                                      int* __restrict__ perm, unsigned* __restrict__ sorted_keys) {
+    __shared__ int s_cnt[NB], s_base[NB];
+    const int M = m_dev ? min(*m_dev, M_bound) : M_bound;
+    const int i0 = blockIdx.x * 4096;
+    if (i0 >= M) return;
+    for (int b = threadIdx.x; b < NB; b += 1024) s_cnt[b] = 0;
+    __syncthreads();
+    unsigned key[4];
+    int bucket[4], rank[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = i0 + j * 1024 + threadIdx.x;
+        bucket[j] = -1;
+        if (i < M) {
+            key[j] = keys[i];
+            bucket[j] = pattern_bucket(key[j]);
+            rank[j] = atomicAdd(&s_cnt[bucket[j]], 1);
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < NB; b += 1024)
+        if (s_cnt[b]) s_base[b] = atomicAdd(&cursor[b], s_cnt[b]);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (bucket[j] < 0) continue;
+        const int pos = s_base[bucket[j]] + rank[j];
+        perm[pos] = i0 + j * 1024 + threadIdx.x;
+        sorted_keys[pos] = key[j];
+    }
+}
+
+// tile_map[b] = tile that workgroup b runs, or -1.  Up to 1024 tiles (every workgroup resident at once): a tile's cost is the number of
+// offsets present in it (thread t folds the 128 patterns of tile t); the tiles are ranked by (cost descending, index) and rank i goes to
+// round i / 256, CU position i % 256 forwards in even rounds and backwards in odd ones.  More tiles than that are dispatched as slots
+// free up, where plain order is as good as any.
+__global__ __launch_bounds__(1024) void k_tile_schedule(const unsigned* __restrict__ sorted_keys, int M_bound, const int* __restrict__ m_dev, int n_blocks,
+                                                        int* __restrict__ tile_map) {
+    __shared__ int s_cost[1024];
+    const int tid = threadIdx.x;
+    const int M = m_dev ? min(*m_dev, M_bound) : M_bound;
+    const int ntile = (M + 127) / 128;
+    for (int b = tid; b < n_blocks; b += 1024) tile_map[b] = -1;
+    __syncthreads();
+    if (ntile > 1024) {
+        for (int t = tid; t < ntile && t < n_blocks; t += 1024) tile_map[t] = t;
+        return;
+    }
+    int c = -1;
+    if (tid < ntile) {
+        unsigned u = 0;
+        const uint4* k4 = (const uint4*)(sorted_keys + (int64_t)tid * 128);   // 512-B aligned: the workspace carve is 256-B aligned
+        const int n = min(128, M - tid * 128);
+        for (int j = 0; j < n / 4; ++j) {
+            const uint4 q = k4[j];
+            u |= q.x | q.y | q.z | q.w;
+        }
+        for (int j = n & ~3; j < n; ++j) u |= sorted_keys[(int64_t)tid * 128 + j];
+        c = __popc(u);
+    }
+    s_cost[tid] = c;
+    __syncthreads();
+    if (tid >= ntile) return;
+    int rank = 0;
+    for (int u = 0; u < ntile; ++u) {
+        const int cu = s_cost[u];
+        rank += (cu > c) || (cu == c && u < tid);
+    }
+    const int r = rank >> 8, pos = rank & 255;
+    const int b = r * 256 + ((r & 1) ? 255 - pos : pos);
+    if (b < n_blocks) tile_map[b] = tid;
+}
+
+struct SchedWs {
+    unsigned *keys, *sorted_keys;
+    int* hist;
+};
+
+int64_t carve(int64_t M, void* ws, SchedWs* out) {
+    const int64_t n = M > 0 ? M : 1;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) {
+        void* p = ws ? (char*)ws + off : nullptr;
+        off += align_up64(bytes, 256);
+        return p;
+    };
+    SchedWs w;
+    w.keys = (unsigned*)take(n * 4);
+    w.sorted_keys = (unsigned*)take(n * 4);
+    w.hist = (int*)take(NB * 4);
+    if (out) *out = w;
+    return off;
+}
+
+}  // namespace
+
+DD3D_API int64_t dd3d_conv_schedule_blocks(int64_t M) { return ceil_div64(ceil_div64(M > 0 ? M : 1, 128), 256) * 256; }
+
+DD3D_API int64_t dd3d_conv_schedule_ws_bytes(int64_t M) { return carve(M, nullptr, nullptr); }
+
+// perm[M] (int32): the rows in pattern order; tile_map[dd3d_conv_schedule_blocks(M)] (int32): workgroup -> tile of that order, or -1.
+// M is a bound when m_dev is given (rows beyond *m_dev sort last and get no tile).
+DD3D_API int dd3d_conv_schedule(const int32_t* nbr, int64_t ld, int K, int64_t M, const int32_t* m_dev, int32_t* perm, int32_t* tile_map, void* ws,
+                                int64_t ws_bytes, void* stream) {
+    if (M < 0 || K <= 0 || K > 27 || ld < M) return DD3D_EARG;
+    if (M >= (1ll << 31) - 256) return DD3D_ESIZE;
+    if (M == 0) return 0;
+    if (!nbr || !perm || !tile_map) return DD3D_EARG;
+    if (!ws || ws_bytes < dd3d_conv_schedule_ws_bytes(M)) return DD3D_EWS;
+    SchedWs w;
+    carve(M, ws, &w);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned nwg = (unsigned)ceil_div64(M, 4096);
+    DD3D_HIP(hipMemsetAsync(w.hist, 0, NB * 4, st));
+    k_row_keys<<<dim3(nwg), 1024, 0, st>>>(nbr, ld, K, (int)M, m_dev, w.keys, w.hist);
+    k_bucket_scan<<<1, 1024, 0, st>>>(w.hist);
+    k_row_scatter<<<dim3(nwg), 1024, 0, st>>>(w.keys, (int)M, m_dev, w.hist, perm, w.sorted_keys);
+    k_tile_schedule<<<1, 1024, 0, st>>>(w.sorted_keys, (int)M, m_dev, (int)dd3d_conv_schedule_blocks(M), tile_map);
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}

@@ -18,6 +18,7 @@ are exactly those that torch autograd produces around MinkowskiEngine's opaque b
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import List, Optional
 
 import numpy as np
@@ -103,6 +104,16 @@ class _Pass:
         W1t = self.W1t = transposed_kernel(conv1.kernel)
         self.params = (W0, W1, w1, b1, w5, b5)
 
+        # Launch schedule of the two large 128-channel convolution launches (forward, backward-data): pattern-sorted rows + balanced
+        # tile placement (dd3d_conv_schedule; results are bit-identical).  It needs the maps only, so it runs on the side stream next to
+        # the first layer; its nodes are ENQUEUED after the first layer's (a HIP graph dispatches its nodes in capture order, and a
+        # branch captured first holds back the one captured after it).
+        use_sched = M1 >= 65536 and os.environ.get("DD3D_CONV_SCHED", "1") != "0"
+        self.sched = None
+        if use_sched:
+            ev_maps = torch.cuda.Event()
+            ev_maps.record(torch.cuda.current_stream(dev))
+
         # ---------------- forward ----------------
         feats = feats.detach().contiguous()
         F0 = self.F0 = _empty((M0, 3), dev)
@@ -114,7 +125,19 @@ class _Pass:
         P0, arg0 = self.P0, self.arg0 = _empty((M1, 128), dev), _empty((M1, 128), dev, _I32)
         L.call("dd3d_affine_relu_pool_fwd", L.ptr(xh0), L.ptr(w1), L.ptr(b1), 1, 128, L.ptr(p0), pl0, 8, M1, c1, L.ptr(P0), L.ptr(arg0), st)
         Y1 = _empty((M1, 128), dev)
-        L.call("dd3d_conv_fwd", L.ptr(P0), M1, 128, L.ptr(W1), 128, L.ptr(k1), ld1, 27, M1, c1, 0, L.ptr(Y1), st)
+        if use_sched:
+            perm1 = _empty((M1,), dev, _I32)
+            tmap1 = _empty((int(L.lib.dd3d_conv_schedule_blocks(M1)),), dev, _I32)
+            self.side.wait_event(ev_maps)
+            with torch.cuda.stream(self.side):
+                ws = L.workspace(int(L.lib.dd3d_conv_schedule_ws_bytes(M1)), dev)
+                L.call("dd3d_conv_schedule", L.ptr(k1), ld1, 27, M1, c1, L.ptr(perm1), L.ptr(tmap1), L.ptr(ws), ws.numel(), L.stream())
+            self.sched = (perm1, tmap1)
+            torch.cuda.current_stream(dev).wait_stream(self.side)
+            L.call("dd3d_conv128_ordered", L.ptr(P0), M1, L.ptr(W1), L.ptr(k1), ld1, 27, M1, c1, 0, L.ptr(self.sched[0]), L.ptr(self.sched[1]),
+                   L.ptr(Y1), st)
+        else:
+            L.call("dd3d_conv_fwd", L.ptr(P0), M1, 128, L.ptr(W1), 128, L.ptr(k1), ld1, 27, M1, c1, 0, L.ptr(Y1), st)
         xh1, is1 = self.xh1, self.is1 = _empty((M1, 128), dev), _empty((B, 128), dev)
         L.call("dd3d_inorm_fwd", L.ptr(Y1), L.ptr(seg2), B, 128, L.ptr(xh1), L.ptr(is1), st)
         P1, arg1 = self.P1, self.arg1 = _empty((M2, 128), dev), _empty((M2, 128), dev, _I32)
@@ -148,7 +171,11 @@ class _Pass:
         with torch.cuda.stream(side):
             g_W1 = self._bww(P0, 128, gY1, k1, ld1, M1, gro2)
         gP0 = _empty((M1, 128), dev)
-        L.call("dd3d_conv_bwd_data", L.ptr(gY1), M1, c1, 128, L.ptr(W1t), 128, L.ptr(k1), ld1, 27, L.ptr(gP0), st)
+        if self.sched is not None:
+            L.call("dd3d_conv128_ordered", L.ptr(gY1), M1, L.ptr(W1t), L.ptr(k1), ld1, 27, M1, c1, 1, L.ptr(self.sched[0]), L.ptr(self.sched[1]),
+                   L.ptr(gP0), st)
+        else:
+            L.call("dd3d_conv_bwd_data", L.ptr(gY1), M1, c1, 128, L.ptr(W1t), 128, L.ptr(k1), ld1, 27, L.ptr(gP0), st)
         gY0, g_w1, g_b1 = self._arp_inorm_bwd(gP0, arg0, cm.parent(2), xh0, is0, w1, b1, seg1, M0, B, G, self.ga0, self.B_syn, True)
         g_W0 = self._bww(F0, 3, gY0, k0, ld0, M0, gro1)
         main.wait_stream(side)

@@ -120,6 +120,23 @@ int dd3d_cloud_maps(const float* coords, const int32_t* pt_off, int B, int max_p
 int dd3d_conv_fwd(const float* X, int64_t M_in, int Cin, const float* W, int Cout, const int32_t* nbr, int64_t ld, int K, int64_t M_out,
                   const int32_t* m_dev, int mirror, float* Y, void* stream);
 
+/* Launch schedule of the Cin = Cout = 128 convolution over one kernel map: perm[M] = the rows sorted (stable radix sort) by their K-bit
+ * pattern of present offsets, so that the 32 rows one wave multiplies together share a pattern and absent offsets are skipped for the
+ * whole block; tile_map[dd3d_conv_schedule_blocks(M)] = workgroup -> 128-row tile of that order (-1 = none), the tiles ranked by
+ * cost and dealt to the CUs in a snake so that the most loaded CU carries the average.  M is a bound when m_dev is given.  One
+ * schedule serves the forward and the mirrored launch.  No counterpart in MinkowskiEngine (its gather-GEMM-scatter compacts per
+ * offset instead); serves MEConv.py:224 like dd3d_conv_fwd. */
+int64_t dd3d_conv_schedule_blocks(int64_t M);
+int64_t dd3d_conv_schedule_ws_bytes(int64_t M);
+int dd3d_conv_schedule(const int32_t* nbr, int64_t ld, int K, int64_t M, const int32_t* m_dev, int32_t* perm, int32_t* tile_map, void* ws,
+                       int64_t ws_bytes, void* stream);
+
+/* dd3d_conv_fwd for Cin = Cout = 128, K = 27 along a schedule: bit-identical output (a row's sum does not depend on the rows it shares
+ * a block with), fewer all-zero rows through the matrix cores, even load over the CUs.
+ * replaces: ConvolutionForwardGPU / ConvolutionBackwardGPU (input gradient, mirror = 1 with the transposed kernel), MEConv.py:224 */
+int dd3d_conv128_ordered(const float* X, int64_t M_in, const float* W, const int32_t* nbr, int64_t ld, int K, int64_t M_out, const int32_t* m_dev,
+                         int mirror, const int32_t* perm, const int32_t* tile_map, float* Y, void* stream);
+
 /* dX[M,Cin] of a stride-1 convolution.  Cin = 128: pass the transposed kernel [K,Cout,Cin]; Cin = 3: pass W itself.
  * replaces: ConvolutionBackwardGPU (input gradient) reached by torch.autograd.grad / loss.backward, mnist_distill.py:349,359,365 */
 int dd3d_conv_bwd_data(const float* dY, int64_t M, const int32_t* m_dev, int Cout, const float* W_or_Wt, int Cin, const int32_t* nbr, int64_t ld,
