@@ -21,8 +21,12 @@ namespace {
 constexpr int NB = 4096;  // hash buckets of the neighbour pattern
 
 __device__ __forceinline__ unsigned row_pattern(const int* __restrict__ nbr, int64_t ld, int K, int row) {
+    int v[27];  // K <= 27: all table reads of the row in flight together
+#pragma unroll
+    for (int k = 0; k < 27; ++k) v[k] = nbr[(int64_t)min(k, K - 1) * ld + row];
     unsigned key = 0;
-    for (int k = 0; k < K; ++k) key |= (unsigned)(nbr[(int64_t)k * ld + row] >= 0) << k;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) key |= (unsigned)(k < K && v[k] >= 0) << k;
     return key;
 }
 __device__ __forceinline__ int pattern_bucket(unsigned key) { return (int)((key * 0x9E3779B1u) >> 20); }
@@ -134,11 +138,15 @@ __global__ __launch_bounds__(1024) void k_tile_schedule(const unsigned* __restri
         unsigned u = 0;
         const uint4* k4 = (const uint4*)(sorted_keys + (int64_t)tid * 128);   // 512-B aligned: the workspace carve is 256-B aligned
         const int n = min(128, M - tid * 128);
-        for (int j = 0; j < n / 4; ++j) {
-            const uint4 q = k4[j];
-            u |= q.x | q.y | q.z | q.w;
+        if (n == 128) {  // 32 independent 16-B loads
+            uint4 q[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) q[j] = k4[j];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) u |= q[j].x | q[j].y | q[j].z | q[j].w;
+        } else {
+            for (int j = 0; j < n; ++j) u |= sorted_keys[(int64_t)tid * 128 + j];
         }
-        for (int j = n & ~3; j < n; ++j) u |= sorted_keys[(int64_t)tid * 128 + j];
         c = __popc(u);
     }
     s_cost[tid] = c;
