@@ -381,3 +381,50 @@ def test_cloud_local_maps_flag_errors():
         CloudCoordinateManager(coords, pt_off, 3, 64, (1, 1, 1)).sync()
     with pytest.raises(ValueError):
         CloudCoordinateManager(coords, pt_off, 3, 100000)
+
+
+def _random_table(M, K, p, seed):
+    """A neighbour table with random partners: the convolution kernels do not care where the rows come from."""
+    g = torch.Generator().manual_seed(seed)
+    nbr = torch.randint(0, M, (K, M), generator=g, dtype=torch.int32)
+    # a few patterns, repeated: rows share neighbour patterns as voxels of strokes do
+    pat = (torch.rand((K, 64), generator=g) < p)
+    nbr[~pat[:, torch.randint(0, 64, (M,), generator=g)]] = -1
+    return nbr
+
+
+@pytest.mark.parametrize("M,bound", [(70001, 70001), (66000, 80000), (3000, 3000), (150000, 150000)])
+def test_scheduled_conv128_is_bit_identical(M, bound):
+    """dd3d_conv_schedule + dd3d_conv128_ordered against dd3d_conv_fwd (itself checked against the oracle above): same bits for the
+    forward and the mirrored launch, with an exact count and with a bound + device-side count; the schedule is a permutation of the rows
+    and covers every tile once.  Sizes on both sides of the 1024-tile limit of the placement."""
+    from dd3d_amd import _lib as L
+    d = dev()
+    nbr = _random_table(bound, 27, 0.4, M).to(d)
+    nbr[nbr >= M] = -1
+    X = torch.randn(bound, 128, generator=torch.Generator().manual_seed(1)).to(d)
+    W = (torch.randn(27, 128, 128, generator=torch.Generator().manual_seed(2)) * 0.05).to(d)
+    m_dev = torch.tensor([M], dtype=torch.int32, device=d) if bound != M else None
+    nblk = int(L.lib.dd3d_conv_schedule_blocks(bound))
+    perm = torch.full((bound,), -7, dtype=torch.int32, device=d)
+    tmap = torch.full((nblk,), -7, dtype=torch.int32, device=d)
+    ws = torch.empty(int(L.lib.dd3d_conv_schedule_ws_bytes(bound)), dtype=torch.uint8, device=d)
+    L.call("dd3d_conv_schedule", L.ptr(nbr), bound, 27, bound, L.ptr(m_dev), L.ptr(perm), L.ptr(tmap), L.ptr(ws), ws.numel(), L.stream())
+    assert sorted(perm[:M].tolist()) == list(range(M))
+    tiles = [t for t in tmap.tolist() if t >= 0]
+    assert sorted(tiles) == list(range((M + 127) // 128)) and min(tmap.tolist()) >= -1
+    for mirror in (0, 1):
+        Y = torch.full((bound, 128), 7.0, device=d)
+        Y2 = torch.full((bound, 128), 7.0, device=d)
+        L.call("dd3d_conv_fwd", L.ptr(X), bound, 128, L.ptr(W), 128, L.ptr(nbr), bound, 27, bound, L.ptr(m_dev), mirror, L.ptr(Y), L.stream())
+        L.call("dd3d_conv128_ordered", L.ptr(X), bound, L.ptr(W), L.ptr(nbr), bound, 27, bound, L.ptr(m_dev), mirror, L.ptr(perm), L.ptr(tmap),
+               L.ptr(Y2), L.stream())
+        assert torch.equal(Y, Y2)
+        assert bool((Y[M:] == 7.0).all())   # rows beyond the device-side count are not touched
+    # the patterns are grouped: fewer (32-row block, offset) products than in row order
+    present = (nbr[:, :M] >= 0)
+    def blocks(order):
+        pm = present[:, order.long()]
+        pm = torch.cat([pm, pm.new_zeros(27, (-M) % 32)], 1)
+        return int(pm.reshape(27, -1, 32).any(2).sum())
+    assert blocks(perm[:M]) < blocks(torch.arange(M, device=d))
