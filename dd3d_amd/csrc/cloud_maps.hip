@@ -11,6 +11,9 @@
 // into row ranges, pass B rebuilds the same tables (deterministic) and emits everything at its global row.  The results are
 // bit-identical to the generic global-hash path in coords.hip (tests/test_gpu_ops.py), which stays for clouds that do not fit in LDS.
 #include "common.h"
+// Barriers: every barrier of the per-cloud kernels orders LDS traffic only (their global accesses are input reads and write-only
+// outputs), so they use lds_barrier() and the output stores stay in flight across them; k_cloud_scan communicates through global
+// memory inside its workgroup and keeps __syncthreads().
 
 namespace {
 
@@ -46,9 +49,9 @@ __device__ __forceinline__ int block_scan(int v, int* total, int* s_w) {
         int t = __shfl_up(incl, o, 64);
         if (lane >= o) incl += t;
     }
-    __syncthreads();  // s_w may still be read by the previous call
+    lds_barrier();  // s_w may still be read by the previous call
     if (lane == 63) s_w[w] = incl;
-    __syncthreads();
+    lds_barrier();
     int base = 0, tot = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -69,7 +72,7 @@ __device__ int lds_unique(const int4* keys, int n, int* tab, int* tmin, int* slo
         tab[i] = -1;
         tmin[i] = 0x7FFFFFFF;
     }
-    __syncthreads();
+    lds_barrier();
     for (int i = tid; i < n; i += CT) {
         const int4 key = keys[i];
         uint32_t h = hash_coord(key) & (HC - 1);
@@ -81,7 +84,7 @@ __device__ int lds_unique(const int4* keys, int n, int* tab, int* tmin, int* slo
         slot[i] = (int)h;
         atomicMin(&tmin[h], i);  // winner among duplicates = first occurrence
     }
-    __syncthreads();
+    lds_barrier();
     int base = 0;
     for (int c0 = 0; c0 < n; c0 += CT) {  // stable compaction of the winners, 256 keys at a time
         const int i = c0 + tid;
@@ -96,9 +99,9 @@ __device__ int lds_unique(const int4* keys, int n, int* tab, int* tmin, int* slo
         }
         base += tot;
     }
-    __syncthreads();
+    lds_barrier();
     for (int i = tid; i < n; i += CT) lid[i] = tab[slot[i]];
-    __syncthreads();
+    lds_barrier();
     return base;
 }
 
@@ -152,7 +155,7 @@ __device__ CloudCounts build_cloud(CloudSmem<NMAX>& S, const float4* __restrict_
         S.q[i] = k;
     }
     if (bad) atomicOr(err, 1);
-    __syncthreads();
+    lds_barrier();
     if (tid < 12) S.box[tid / 6][tid % 6] = (tid % 6) < 3 ? 0x7FFFFFFF : (int)0x80000000;
     CloudCounts c;
     c.m1 = lds_unique<HC>(S.q, n, S.tab1, S.tmin, S.slot, S.U1, S.lid1, S.first1, S.s_w);
@@ -167,7 +170,7 @@ __device__ CloudCounts build_cloud(CloudSmem<NMAX>& S, const float4* __restrict_
         }
         box_merge(S.box[0], lo0, lo1, lo2, hi0, hi1, hi2);
     }
-    __syncthreads();
+    lds_barrier();
     c.m2 = lds_unique<HC>(S.q, c.m1, S.tab2, S.tmin, S.slot, S.U2, S.par2, S.first2, S.s_w);
     {
         int lo0 = 0x7FFFFFFF, lo1 = lo0, lo2 = lo0, hi0 = (int)0x80000000, hi1 = hi0, hi2 = hi0;
@@ -179,7 +182,7 @@ __device__ CloudCounts build_cloud(CloudSmem<NMAX>& S, const float4* __restrict_
         }
         box_merge(S.box[1], lo0, lo1, lo2, hi0, hi1, hi2);
     }
-    __syncthreads();
+    lds_barrier();
     c.m4 = lds_unique<HC>(S.q, c.m2, S.tab4, S.tmin, S.slot, S.U4, S.par4, S.first4, S.s_w);
     *n_out = n;
     return c;
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(CT) void k_cloud_count(const float4* __restrict__ c
         S.q[i] = k;
     }
     if (bad) atomicOr(err, 1);
-    __syncthreads();
+    lds_barrier();
     const int big = 0x7F7F7F7F;
     int a = big, d = big, e = big;
     int won1 = 0, won2 = 0, won4 = 0;
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(CT) void k_cloud_count(const float4* __restrict__ c
         atomicMin(&S.s_w[4], d);
         atomicMin(&S.s_w[5], e);
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < 3) {
         cnt[tid * B + b] = S.s_w[tid];
         // one global atomic per cloud and axis, and only when it can lower the group's corner (most clouds share it): the values only
@@ -358,9 +361,9 @@ __global__ __launch_bounds__(CT) void k_cloud_emit(const float4* __restrict__ co
     for (int i = tid; i < n; i += CT) o.inv1[p0 + i] = r1 + S.lid1[i];
     // voxel -> points CSR (local counting sort; the tiny lists are put in ascending point order afterwards)
     for (int v = tid; v <= c.m1; v += CT) S.cnt[v] = 0;
-    __syncthreads();
+    lds_barrier();
     for (int i = tid; i < n; i += CT) atomicAdd(&S.cnt[S.lid1[i]], 1);
-    __syncthreads();
+    lds_barrier();
     {   // exclusive scan of cnt[0..m1) in place, 256 at a time; S.slot becomes the write cursor
         int carry = 0;
         for (int c0 = 0; c0 < c.m1; c0 += CT) {
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(CT) void k_cloud_emit(const float4* __restrict__ co
         }
         if (tid == 0) S.cnt[c.m1] = carry;
     }
-    __syncthreads();
+    lds_barrier();
     for (int v = tid; v < c.m1; v += CT) o.vox_off[r1 + v] = p0 + S.cnt[v];
     if (tid == 0) o.vox_off[r1 + c.m1] = p0 + n;  // = the next cloud's first entry; the last cloud closes the array
     int* lpts = reinterpret_cast<int*>(S.q);       // q is free: local point lists
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(CT) void k_cloud_emit(const float4* __restrict__ co
         const int v = S.lid1[i];
         lpts[S.cnt[v] + atomicAdd(&S.slot[v], 1)] = i;
     }
-    __syncthreads();
+    lds_barrier();
     for (int v = tid; v < c.m1; v += CT) {
         const int a = S.cnt[v], e = S.cnt[v + 1];
         for (int i = a + 1; i < e; ++i) {
