@@ -2,6 +2,7 @@
 // affine + ReLU + max-pool (N7 affine, N8, N9) with their backward passes.  C (channels) is 128 for the norm/pool kernels:
 // one row = 512 B = 32 lanes x float4, so every row access is a fully coalesced 512-B segment.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -83,6 +84,30 @@ __device__ __forceinline__ f32x4 cloud_colsum(f32x4 v, f32x4* s_red /*[RL*CL/64 
     for (int j = 1; j < NW; ++j) s += s_red[j * CL + cl];
     __syncthreads();
     return s;
+}
+
+// NV column sums at once (one LDS exchange and two barriers instead of NV of each): same fold order as cloud_colsum per quantity.
+template <int RL, int CL, int NV>
+__device__ __forceinline__ void cloud_colsums(f32x4 (&v)[NV], f32x4* s_red /*[NV][RL*CL/64 * CL]*/) {
+    constexpr int NW = RL * CL / 64;
+    const int cl = threadIdx.x % CL, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+#pragma unroll
+        for (int o = CL; o < 64; o <<= 1)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[q][j] += __shfl_xor(v[q][j], o, 64);
+        if (lane < CL) s_red[(q * NW + w) * CL + lane] = v[q];
+    }
+    lds_barrier();
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        f32x4 s = s_red[(q * NW) * CL + cl];
+#pragma unroll 2
+        for (int j = 1; j < NW; ++j) s += s_red[(q * NW + j) * CL + cl];
+        v[q] = s;
+    }
+    lds_barrier();
 }
 
 template <int RL, int CACHE>
@@ -295,7 +320,7 @@ __global__ __launch_bounds__(256) void k_arp_reduce(const f32x4* __restrict__ pa
 // round trip of g_xhat through HBM): the thread's rows of g_xhat and xhat stay in registers between the statistics and the final
 // write.  Per-cloud partial sums of ga*xhat / ga go to part[b][2][32]; k_cloud_group_sum folds them per group in cloud order.
 // grid (cloud, 32 / CL): a workgroup takes CL float4 channel-lanes (CL * 16 B of every row), so several workgroups per CU overlap
-// their gather latencies
+// their gather latencies (CL = 8: 128-B pieces of a row, one cache line)
 template <int RL, int CACHE, int CL>
 __global__ __launch_bounds__(RL * CL) void k_arp_inorm_bwd(const f32x4* __restrict__ g_pool, const int4* __restrict__ arg, const int* __restrict__ parent,
                                                            const f32x4* __restrict__ xhat, const f32x4* __restrict__ inv_std,
@@ -304,7 +329,7 @@ __global__ __launch_bounds__(RL * CL) void k_arp_inorm_bwd(const f32x4* __restri
                                                            f32x4* __restrict__ dY, f32x4* __restrict__ ga_out_all, int ga_clouds,
                                                            const f32x4* __restrict__ ga_prev, const f32x4* __restrict__ gw_extra,
                                                            f32x4* __restrict__ part /*[B][2][32] or null*/) {
-    __shared__ f32x4 s_red[RL * CL];
+    __shared__ f32x4 s_red[4 * (RL * CL / 64) * CL];
     const int b = blockIdx.x, c4 = blockIdx.y * CL + threadIdx.x % CL, rl = threadIdx.x / CL;
     const int r0 = seg_off[b], r1 = seg_off[b + 1];
     const int n = r1 - r0;
@@ -360,15 +385,21 @@ __global__ __launch_bounds__(RL * CL) void k_arp_inorm_bwd(const f32x4* __restri
         s1 += gx;
         s2 += gx * xh;
     }
-    const f32x4 m1 = cloud_colsum<RL, CL>(s1, s_red) / (float)n;
-    const f32x4 m2 = cloud_colsum<RL, CL>(s2, s_red) / (float)n;
-    if (part) {
-        const f32x4 tw = cloud_colsum<RL, CL>(sw, s_red);
-        const f32x4 tb = cloud_colsum<RL, CL>(sb, s_red);
+    f32x4 m1, m2;
+    if (part) {  // all four column sums in one exchange (part is a kernel argument: the branch is uniform)
+        f32x4 v[4] = {s1, s2, sw, sb};
+        cloud_colsums<RL, CL, 4>(v, s_red);
+        m1 = v[0] / (float)n;
+        m2 = v[1] / (float)n;
         if (rl == 0) {
-            part[((int64_t)b * 2 + 0) * 32 + c4] = tw;
-            part[((int64_t)b * 2 + 1) * 32 + c4] = tb;
+            part[((int64_t)b * 2 + 0) * 32 + c4] = v[2];
+            part[((int64_t)b * 2 + 1) * 32 + c4] = v[3];
         }
+    } else {
+        f32x4 v[2] = {s1, s2};
+        cloud_colsums<RL, CL, 2>(v, s_red);
+        m1 = v[0] / (float)n;
+        m2 = v[1] / (float)n;
     }
     #pragma unroll
     for (int i = 0; i < CACHE; ++i) {
@@ -519,9 +550,11 @@ DD3D_API int dd3d_arp_inorm_bwd(const float* g_pool, const int32_t* arg, const i
     hipStream_t st = (hipStream_t)stream;
     if (B > 0) {
         if (!g_pool || !arg || !parent || !xhat || !inv_std || !seg_off || !dY) return DD3D_EARG;
-        k_arp_inorm_bwd<32, 4, 16><<<dim3(B, 2), 512, 0, st>>>((const f32x4*)g_pool, (const int4*)arg, parent, (const f32x4*)xhat, (const f32x4*)inv_std,
-                                                        (const f32x4*)w, (const f32x4*)b, seg_off, cloud_group, (f32x4*)dY, (f32x4*)ga_out, ga_clouds,
-                                                        (const f32x4*)ga_prev, (const f32x4*)gw_extra, gw_w ? (f32x4*)ws : nullptr);
+        // 32 row-lanes x 8 float4 channel-lanes per workgroup, four workgroups per cloud (measured against 512- and 1024-thread shapes:
+        // more, smaller workgroups per CU overlap their gather chains best)
+        k_arp_inorm_bwd<32, 4, 8><<<dim3(B, 4), 256, 0, st>>>((const f32x4*)g_pool, (const int4*)arg, parent, (const f32x4*)xhat, (const f32x4*)inv_std,
+                                                       (const f32x4*)w, (const f32x4*)b, seg_off, cloud_group, (f32x4*)dY, (f32x4*)ga_out, ga_clouds,
+                                                       (const f32x4*)ga_prev, (const f32x4*)gw_extra, gw_w ? (f32x4*)ws : nullptr);
     }
     if (gw_w) k_cloud_group_sum<<<dim3(G), 1024, 0, st>>>((const f32x4*)ws, group_cloud_off, (f32x4*)gw_w, (f32x4*)gw_b);
     DD3D_CHECK_LAUNCH();
