@@ -21,7 +21,9 @@ constexpr int CT = 256;  // threads per cloud
 
 template <int NMAX>
 struct CloudSmem {
-    static constexpr int HC = 2 * NMAX;  // table capacity: load factor <= 0.5, so every probe sequence meets an empty slot
+    // table capacity: load factor <= 0.5, so every probe sequence meets an empty slot; small clouds get 4 slots per point, which also lets
+    // a 28 x 28 pixel grid (784 cells) be addressed DIRECTLY (see Cells)
+    static constexpr int HC = NMAX <= 256 ? 4 * NMAX : 2 * NMAX;
     int4 q[NMAX];                        // floored point coordinates
     int4 U1[NMAX], U2[NMAX], U4[NMAX];   // unique coordinates at strides 1, 2, 4 (first-occurrence order)
     int tab1[HC], tab2[HC], tab4[HC];    // coordinate -> local voxel id, linear probing, -1 = empty
@@ -63,10 +65,29 @@ __device__ __forceinline__ int block_scan(int v, int* total, int* s_w) {
     return base + incl - v;
 }
 
+// When the bounding box of a table's keys has no more cells than the table has slots, a key's slot is its cell: no hashing, no probing,
+// no key compare (flat 28 x 28 digit clouds: 784 / 196 / 49 cells at strides 1 / 2 / 4).  Otherwise (3-D clouds) the table is a
+// linear-probing hash.  Both give the same voxel order and maps -- the slot never leaves the table.
+struct Cells {
+    int lo0, lo1, lo2, n1, n2, sh, direct;
+};
+__device__ __forceinline__ Cells cells_of(const int* box /*lo[3], hi[3]*/, int sh, int HC) {
+    Cells c;
+    c.lo0 = box[0]; c.lo1 = box[1]; c.lo2 = box[2]; c.sh = sh;
+    const long long n0 = (((long long)box[3] - box[0]) >> sh) + 1, n1 = (((long long)box[4] - box[1]) >> sh) + 1,
+                    n2 = (((long long)box[5] - box[2]) >> sh) + 1;
+    c.n1 = (int)n1; c.n2 = (int)n2;
+    c.direct = n0 > 0 && n1 > 0 && n2 > 0 && n0 <= HC && n1 <= HC && n2 <= HC && n0 * n1 * n2 <= HC;
+    return c;
+}
+__device__ __forceinline__ int cell_of(const Cells& c, int4 key) {  // key inside the box, aligned to the stride
+    return (((key.y - c.lo0) >> c.sh) * c.n1 + ((key.z - c.lo1) >> c.sh)) * c.n2 + ((key.w - c.lo2) >> c.sh);
+}
+
 // Unique keys[0..n) in first-occurrence order -> U[0..count); tab maps a coordinate to its index in U afterwards;
 // lid[i] = index in U of keys[i]; first_idx[r] (nullable) = smallest i with keys[i] == U[r].  Returns count (block-uniform).
 template <int HC>
-__device__ int lds_unique(const int4* keys, int n, int* tab, int* tmin, int* slot, int4* U, int* lid, int* first_idx, int* s_w) {
+__device__ int lds_unique(const int4* keys, int n, const Cells cells, int* tab, int* tmin, int* slot, int4* U, int* lid, int* first_idx, int* s_w) {
     const int tid = threadIdx.x;
     for (int i = tid; i < HC; i += CT) {
         tab[i] = -1;
@@ -75,8 +96,8 @@ __device__ int lds_unique(const int4* keys, int n, int* tab, int* tmin, int* slo
     lds_barrier();
     for (int i = tid; i < n; i += CT) {
         const int4 key = keys[i];
-        uint32_t h = hash_coord(key) & (HC - 1);
-        for (;;) {
+        uint32_t h = cells.direct ? (uint32_t)cell_of(cells, key) : hash_coord(key) & (HC - 1);
+        for (;;) {  // direct cells: the first slot is the key's own (empty, or a duplicate of the key)
             int old = atomicCAS(&tab[h], -1, i);
             if (old == -1 || coord_eq(keys[old], key)) break;
             h = (h + 1) & (HC - 1);
@@ -93,14 +114,17 @@ __device__ int lds_unique(const int4* keys, int n, int* tab, int* tmin, int* slo
         const int ex = block_scan(first ? 1 : 0, &tot, s_w);
         if (first) {
             const int r = base + ex;
-            U[r] = keys[i];
+            const int4 key = keys[i];
+            U[r] = key;
             if (first_idx) first_idx[r] = i;
-            tab[slot[i]] = r;  // all inserts are done: the slot now holds the voxel id, keys live in U
+            // all inserts are done: the slot now holds the voxel id (low 10 bits; NMAX <= 1024) under 21 bits of the key's hash, so a
+            // hashed lookup rejects a foreign slot from the one word it has already read; keys live in U
+            tab[slot[i]] = cells.direct ? r : (int)(((hash_coord(key) >> 11) & 0x1FFFFFu) << 10) | r;
         }
         base += tot;
     }
     lds_barrier();
-    for (int i = tid; i < n; i += CT) lid[i] = tab[slot[i]];
+    for (int i = tid; i < n; i += CT) lid[i] = tab[slot[i]] & 1023;
     lds_barrier();
     return base;
 }
@@ -108,13 +132,19 @@ __device__ int lds_unique(const int4* keys, int n, int* tab, int* tmin, int* slo
 // A key outside the bounding box of the table's voxels cannot be present: no probe.  Flat clouds (MNIST digits: depth 0) lose every
 // offset with a displacement along the flat axis this way -- 18 of the 27 kernel-map offsets, half of the pooling offsets.
 template <int HC>
-__device__ __forceinline__ int lds_lookup(const int* tab, const int4* U, const int* box, int4 key) {
+__device__ __forceinline__ int lds_lookup(const int* tab, const int4* U, const int* box, const Cells& cells, int4 key) {
     if (key.y < box[0] || key.y > box[3] || key.z < box[1] || key.z > box[4] || key.w < box[2] || key.w > box[5]) return -1;
-    uint32_t h = hash_coord(key) & (HC - 1);
+    if (cells.direct) {
+        const int e = tab[cell_of(cells, key)];
+        return e < 0 ? -1 : e;
+    }
+    const uint32_t hk = hash_coord(key);
+    const int tag = (int)((hk >> 11) & 0x1FFFFFu);
+    uint32_t h = hk & (HC - 1);
     for (;;) {
-        const int r = tab[h];
-        if (r < 0) return -1;
-        if (coord_eq(U[r], key)) return r;
+        const int e = tab[h];
+        if (e < 0) return -1;
+        if ((e >> 10) == tag && coord_eq(U[e & 1023], key)) return e & 1023;  // the key itself is read only behind a matching tag
         h = (h + 1) & (HC - 1);
     }
 }
@@ -139,7 +169,8 @@ struct CloudCounts {
 // load + floor the cloud's points, then the three unique levels.  Sets *err |= 1 if a point's batch column is not b,
 // |= 8 if the cloud has more than NMAX points (it is truncated: results are then meaningless but nothing goes out of bounds).
 template <int NMAX>
-__device__ CloudCounts build_cloud(CloudSmem<NMAX>& S, const float4* __restrict__ coords, int p0, int n_raw, int b, int* err, int* n_out) {
+__device__ CloudCounts build_cloud(CloudSmem<NMAX>& S, const float4* __restrict__ coords, int p0, int n_raw, int b, int* err, int* n_out, Cells* cells1_out,
+                                   Cells* cells2_out) {
     constexpr int HC = CloudSmem<NMAX>::HC;
     const int tid = threadIdx.x;
     int n = n_raw;
@@ -147,43 +178,42 @@ __device__ CloudCounts build_cloud(CloudSmem<NMAX>& S, const float4* __restrict_
         n = NMAX;
         if (tid == 0) atomicOr(err, 8);
     }
+    if (tid < 12) S.box[tid / 6][tid % 6] = (tid % 6) < 3 ? 0x7FFFFFFF : (int)0x80000000;
+    lds_barrier();
     bool bad = false;
-    for (int i = tid; i < n; i += CT) {
-        const float4 c = coords[p0 + i];
-        const int4 k = make_int4((int)floorf(c.x), (int)floorf(c.y), (int)floorf(c.z), (int)floorf(c.w));
-        bad |= k.x != b;
-        S.q[i] = k;
+    {
+        int lo0 = 0x7FFFFFFF, lo1 = lo0, lo2 = lo0, hi0 = (int)0x80000000, hi1 = hi0, hi2 = hi0;
+        for (int i = tid; i < n; i += CT) {
+            const float4 c = coords[p0 + i];
+            const int4 k = make_int4((int)floorf(c.x), (int)floorf(c.y), (int)floorf(c.z), (int)floorf(c.w));
+            bad |= k.x != b;
+            S.q[i] = k;
+            lo0 = min(lo0, k.y); lo1 = min(lo1, k.z); lo2 = min(lo2, k.w);
+            hi0 = max(hi0, k.y); hi1 = max(hi1, k.z); hi2 = max(hi2, k.w);
+        }
+        box_merge(S.box[0], lo0, lo1, lo2, hi0, hi1, hi2);  // box of the stride-1 voxels = box of the floored points
     }
     if (bad) atomicOr(err, 1);
     lds_barrier();
-    if (tid < 12) S.box[tid / 6][tid % 6] = (tid % 6) < 3 ? 0x7FFFFFFF : (int)0x80000000;
+    // the stride-2 voxels' box follows from it (floor is monotone); likewise the stride-4 box, which only sizes the third table
+    if (tid < 6) S.box[1][tid] = floor_div_i(S.box[0][tid], 2) * 2;
+    lds_barrier();
+    int box4[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) box4[j] = floor_div_i(S.box[1][j], 4) * 4;
+    const Cells cells1 = cells_of(S.box[0], 0, HC), cells2 = cells_of(S.box[1], 1, HC);
+    *cells1_out = cells1;
+    *cells2_out = cells2;
+    const Cells cells4 = cells_of(box4, 2, HC);
     CloudCounts c;
-    c.m1 = lds_unique<HC>(S.q, n, S.tab1, S.tmin, S.slot, S.U1, S.lid1, S.first1, S.s_w);
+    c.m1 = lds_unique<HC>(S.q, n, cells1, S.tab1, S.tmin, S.slot, S.U1, S.lid1, S.first1, S.s_w);
     // stride 2: keys = stride-2 coordinate of every stride-1 voxel (q is free again and serves as key storage)
-    {
-        int lo0 = 0x7FFFFFFF, lo1 = lo0, lo2 = lo0, hi0 = (int)0x80000000, hi1 = hi0, hi2 = hi0;
-        for (int v = tid; v < c.m1; v += CT) {
-            const int4 u = S.U1[v];
-            S.q[v] = stride_coord(u, 2);
-            lo0 = min(lo0, u.y); lo1 = min(lo1, u.z); lo2 = min(lo2, u.w);
-            hi0 = max(hi0, u.y); hi1 = max(hi1, u.z); hi2 = max(hi2, u.w);
-        }
-        box_merge(S.box[0], lo0, lo1, lo2, hi0, hi1, hi2);
-    }
+    for (int v = tid; v < c.m1; v += CT) S.q[v] = stride_coord(S.U1[v], 2);
     lds_barrier();
-    c.m2 = lds_unique<HC>(S.q, c.m1, S.tab2, S.tmin, S.slot, S.U2, S.par2, S.first2, S.s_w);
-    {
-        int lo0 = 0x7FFFFFFF, lo1 = lo0, lo2 = lo0, hi0 = (int)0x80000000, hi1 = hi0, hi2 = hi0;
-        for (int v = tid; v < c.m2; v += CT) {
-            const int4 u = S.U2[v];
-            S.q[v] = stride_coord(u, 4);
-            lo0 = min(lo0, u.y); lo1 = min(lo1, u.z); lo2 = min(lo2, u.w);
-            hi0 = max(hi0, u.y); hi1 = max(hi1, u.z); hi2 = max(hi2, u.w);
-        }
-        box_merge(S.box[1], lo0, lo1, lo2, hi0, hi1, hi2);
-    }
+    c.m2 = lds_unique<HC>(S.q, c.m1, cells2, S.tab2, S.tmin, S.slot, S.U2, S.par2, S.first2, S.s_w);
+    for (int v = tid; v < c.m2; v += CT) S.q[v] = stride_coord(S.U2[v], 4);
     lds_barrier();
-    c.m4 = lds_unique<HC>(S.q, c.m2, S.tab4, S.tmin, S.slot, S.U4, S.par4, S.first4, S.s_w);
+    c.m4 = lds_unique<HC>(S.q, c.m2, cells4, S.tab4, S.tmin, S.slot, S.U4, S.par4, S.first4, S.s_w);
     *n_out = n;
     return c;
 }
@@ -349,7 +379,8 @@ __global__ __launch_bounds__(CT) void k_cloud_emit(const float4* __restrict__ co
     const int b = blockIdx.x, tid = threadIdx.x;
     const int p0 = pt_off[b];
     int n;
-    const CloudCounts c = build_cloud<NMAX>(S, coords, p0, pt_off[b + 1] - p0, b, err, &n);
+    Cells cells1, cells2;
+    const CloudCounts c = build_cloud<NMAX>(S, coords, p0, pt_off[b + 1] - p0, b, err, &n, &cells1, &cells2);
     const int r1 = seg[b], r2 = seg[(B + 1) + b], r4 = seg[2 * (B + 1) + b];
 
     // stride 1: coordinates, first point, inverse map
@@ -417,7 +448,7 @@ __global__ __launch_bounds__(CT) void k_cloud_emit(const float4* __restrict__ co
         int d0, d1, d2;
         k3_offset(k, 1, &d0, &d1, &d2);
         const int4 u = S.U1[v];
-        const int r = lds_lookup<HC>(S.tab1, S.U1, S.box[0], make_int4(u.x, u.y + d0, u.z + d1, u.w + d2));
+        const int r = lds_lookup<HC>(S.tab1, S.U1, S.box[0], cells1, make_int4(u.x, u.y + d0, u.z + d1, u.w + d2));
         o.nbr1[(int64_t)k * o.ld + r1 + v] = r < 0 ? -1 : r1 + r;
     }
     for (int idx = tid; idx < 27 * c.m2; idx += CT) {
@@ -425,20 +456,20 @@ __global__ __launch_bounds__(CT) void k_cloud_emit(const float4* __restrict__ co
         int d0, d1, d2;
         k3_offset(k, 2, &d0, &d1, &d2);
         const int4 u = S.U2[v];
-        const int r = lds_lookup<HC>(S.tab2, S.U2, S.box[1], make_int4(u.x, u.y + d0, u.z + d1, u.w + d2));
+        const int r = lds_lookup<HC>(S.tab2, S.U2, S.box[1], cells2, make_int4(u.x, u.y + d0, u.z + d1, u.w + d2));
         o.nbr2[(int64_t)k * o.ld + r2 + v] = r < 0 ? -1 : r2 + r;
     }
     // k=2 pooling maps: children of a stride-2s voxel at offsets {0,1}*s, k = e0 + 2 e1 + 4 e2
     for (int idx = tid; idx < 8 * c.m2; idx += CT) {
         const int k = idx / c.m2, v = idx - k * c.m2;
         const int4 u = S.U2[v];
-        const int r = lds_lookup<HC>(S.tab1, S.U1, S.box[0], make_int4(u.x, u.y + (k & 1), u.z + ((k >> 1) & 1), u.w + (k >> 2)));
+        const int r = lds_lookup<HC>(S.tab1, S.U1, S.box[0], cells1, make_int4(u.x, u.y + (k & 1), u.z + ((k >> 1) & 1), u.w + (k >> 2)));
         o.kid2[(int64_t)k * o.ld + r2 + v] = r < 0 ? -1 : r1 + r;
     }
     for (int idx = tid; idx < 8 * c.m4; idx += CT) {
         const int k = idx / c.m4, v = idx - k * c.m4;
         const int4 u = S.U4[v];
-        const int r = lds_lookup<HC>(S.tab2, S.U2, S.box[1], make_int4(u.x, u.y + 2 * (k & 1), u.z + 2 * ((k >> 1) & 1), u.w + 2 * (k >> 2)));
+        const int r = lds_lookup<HC>(S.tab2, S.U2, S.box[1], cells2, make_int4(u.x, u.y + 2 * (k & 1), u.z + 2 * ((k >> 1) & 1), u.w + 2 * (k >> 2)));
         o.kid4[(int64_t)k * o.ld + r4 + v] = r < 0 ? -1 : r2 + r;
     }
     // dense() placement of the stride-4 voxels: site = flat index relative to the group's minimum corner
