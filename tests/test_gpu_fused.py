@@ -152,15 +152,17 @@ def test_gather_clouds_equals_collate():
         assert int(err.item()) == 4
 
 
+@pytest.mark.parametrize("classes", [None, [1, 3]])
 @pytest.mark.parametrize("metric", ["modmse", "ours"])
-def test_graph_replay_is_bitwise_the_eager_step(metric):
+def test_graph_replay_is_bitwise_the_eager_step(metric, classes):
     """The captured HIP graph (bound-sized launches, device-side row counts, on-device batch assembly) against the eager step with
     exact sizes: same seed => the same samples => bit-identical losses and synthetic points over several steps of different sizes."""
     from dd3d_amd.fused_step import FusedDistiller
     from dd3d_amd.synthetic import mnist3d_like
     images, _, idx = mnist3d_like(4, 40, seed=3)
     syn = init_synthetic(4, 3, 250, seed=1)
-    kw = dict(ipc=3, num_classes=4, batch_size=24, dist_opt=metric, device=DEV, seed=11, image_syn=syn)
+    # classes=[1, 3]: a rank's share of a class-sharded job -- the one-launch prologue / epilogue then touch the owned clouds only
+    kw = dict(ipc=3, num_classes=4, batch_size=24, dist_opt=metric, device=DEV, seed=11, image_syn=syn, classes=classes)
     fg = FusedDistiller(images, idx, _net(), graph=True, **kw)
     fe = FusedDistiller(images, idx, _net(), graph=False, **kw)
     sizes = set()
@@ -169,6 +171,11 @@ def test_graph_replay_is_bitwise_the_eager_step(metric):
         assert lg == le, f"step {step}: graph {lg} vs eager {le}"
         assert torch.equal(fg.image_syn, fe.image_syn)
         assert torch.equal(fg.last["grad"], fe.last["grad"])
+        if classes is not None:   # the other ranks' clouds: clamped, never moved, zero gradient
+            other = [c * 3 + j for c in range(4) if c not in classes for j in range(3)]
+            ref = syn[other].to(DEV).clamp(0, 27)
+            ref[:, :, 0] = 0
+            assert torch.equal(fg.image_syn[other], ref) and float(fg.last["grad"][other].abs().sum()) == 0.0
         sizes.add(fg.row_counts()[0])
     fg.check()
     assert fg._graph is not None and len(sizes) > 1  # the graph really replayed over batches of different sizes
