@@ -82,7 +82,16 @@ __global__ void k_sl_fwd_sum(const float* __restrict__ part, const int* __restri
     if (t >= B * J) return;
     const int b = t / J, j = t - b * J;
     float s = 0.f;
-    for (int v = seg_off[b]; v < seg_off[b + 1]; ++v) s += part[(int64_t)v * J + j];
+    int v = seg_off[b];
+    const int v1 = seg_off[b + 1];
+    for (; v + 8 <= v1; v += 8) {  // eight loads in flight, added in row order (same sum, bit for bit, as one by one)
+        float x[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[q] = part[(int64_t)(v + q) * J + j];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += x[q];
+    }
+    for (; v < v1; ++v) s += part[(int64_t)v * J + j];
     out[t] = bias ? s + bias[j] : s;
 }
 
@@ -366,7 +375,15 @@ __global__ __launch_bounds__(256) void k_gd_finalize(const GPlan p, const float4
             int row = gr - p.row_off[s];
             int nch = p.nchunk[s];
             const float4* pp = partial + p.part_off[s] + (int64_t)row * nch;
-            for (int c = 0; c < nch; ++c) {
+            int c = 0;
+            for (; c + 4 <= nch; c += 4) {  // four loads in flight, added in chunk order
+                float4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = pp[c + q];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { st.x += v[q].x; st.y += v[q].y; st.z += v[q].z; st.w += v[q].w; }
+            }
+            for (; c < nch; ++c) {
                 float4 v = pp[c];
                 st.x += v.x; st.y += v.y; st.z += v.z; st.w += v.w;
             }
