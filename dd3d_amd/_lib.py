@@ -48,6 +48,7 @@ _SIGS = {
     "dd3d_syn_head": (I32, [P, I64, I32, P, I32, F32, F32, I32, F32, P, P, P]),
     "dd3d_sgd_scatter": (I32, [P, P, P, P, I64, I32, F32, F32, P, P]),
     "dd3d_populate_img": (I32, [P, I64, I64, I32, I32, P, P, P]),
+    "dd3d_conv_schedule_tile_rows": (I32, [I64]),
     "dd3d_conv_schedule_blocks": (I64, [I64]),
     "dd3d_conv_schedule_ws_bytes": (I64, [I64]),
     "dd3d_conv_schedule": (I32, [P, I64, I32, I64, P, P, P, P, I64, P]),

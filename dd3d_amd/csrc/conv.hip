@@ -36,13 +36,15 @@ inline int64_t max_slots128(int64_t bound, int G) { return ceil_div64(bound, 128
 // ---------------------------------------------------------------------------------------------
 template <int TM, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256) void k_conv128(const float* __restrict__ X, const float* __restrict__ W, const int* __restrict__ nbr, int64_t ld,
-                                                 int K, int M_bound, const int* __restrict__ m_dev, int mirror, float* __restrict__ Y, int xcd_remap) {
+                                                 int K, int M_bound, const int* __restrict__ m_dev, int mirror, float* __restrict__ Y, int xcd_remap,
+                                                 const int* __restrict__ perm = nullptr, const int* __restrict__ tile_map = nullptr) {
     constexpr int BK = 32, LDA4 = 9 /* (BK+4)/4 float4 per A row: +16 B pad keeps ds_read_b128 conflict-free */;
     constexpr int WM = TM / WAVES_M, WN = 128 / WAVES_N, MT = WM / 32, NT = WN / 32;
     static_assert(WAVES_M * WAVES_N == 4 && MT >= 1 && NT >= 1, "4 waves");
     __shared__ f32x4 As4[TM * LDA4];
     __shared__ f32x4 Bs4[BK * 32];
     __shared__ int s_nbr[27 * TM];
+    __shared__ int s_row[TM];  // output row of each tile slot: row0 + r, or perm[row0 + r] for a scheduled launch (sched.hip)
     __shared__ unsigned s_kmask;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -52,16 +54,24 @@ __global__ __launch_bounds__(256) void k_conv128(const float* __restrict__ X, co
     // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so XCD x takes the x-th
     // contiguous eighth of the tiles: neighbouring tiles (whose gathers overlap) then share one L2 instead of eight.
     const int ntile = (M_out + TM - 1) / TM, per_xcd = (ntile + 7) / 8;
-    const int tile = xcd_remap ? (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    int tile = (xcd_remap && !tile_map) ? (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (tile_map) {
+        tile = tile_map[blockIdx.x];
+        if (tile < 0) return;
+    }
     const int64_t row0 = (int64_t)tile * TM;
-    if (tile >= ntile || (xcd_remap && (int)(blockIdx.x >> 3) >= per_xcd)) return;
+    if (tile >= ntile || (!tile_map && xcd_remap && (int)(blockIdx.x >> 3) >= per_xcd)) return;
 
     if (tid == 0) s_kmask = 0;
+    if (tid < TM) {
+        const int64_t slot = row0 + tid;
+        s_row[tid] = slot < M_out ? (perm ? perm[slot] : (int)slot) : M_out;
+    }
     __syncthreads();
     unsigned mymask = 0;
     for (int idx = tid; idx < K * TM; idx += 256) {
         int k = idx / TM, r = idx - k * TM;
-        int64_t row = row0 + r;
+        const int row = s_row[r];
         int ks = mirror ? K - 1 - k : k;
         int v = row < M_out ? nbr[(int64_t)ks * ld + row] : -1;
         s_nbr[idx] = v;
@@ -164,7 +174,7 @@ __global__ __launch_bounds__(256) void k_conv128(const float* __restrict__ X, co
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                int64_t row = row0 + wrow0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int64_t row = s_row[wrow0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
                 if (row < M_out) Y[row * 128 + wcol0 + n * 32 + i32] = acc[m][n][r];
             }
 }
@@ -797,14 +807,18 @@ DD3D_API int dd3d_conv_fwd(const float* X, int64_t M_in, int Cin, const float* W
 // workgroup b on tile tile_map[b].  Same result as dd3d_conv_fwd, bit for bit; fewer all-zero rows through the matrix cores and an even
 // load over the CUs.
 DD3D_API int64_t dd3d_conv_schedule_blocks(int64_t M);
+DD3D_API int dd3d_conv_schedule_tile_rows(int64_t M);
 DD3D_API int dd3d_conv128_ordered(const float* X, int64_t M_in, const float* W, const int32_t* nbr, int64_t ld, int K, int64_t M_out, const int32_t* m_dev,
                                   int mirror, const int32_t* perm, const int32_t* tile_map, float* Y, void* stream) {
     if (M_out < 0 || M_in < 0 || K != 27 || ld < M_out) return DD3D_EARG;
     if (M_out >= (1ll << 31) / 128 * 16) return DD3D_ESIZE;
     if (M_out == 0) return 0;
     if (!X || !W || !nbr || !Y || !perm || !tile_map) return DD3D_EARG;
-    k_conv128_rows<4><<<dim3((unsigned)dd3d_conv_schedule_blocks(M_out)), 256, 0, (hipStream_t)stream>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, 0, perm,
-                                                                                                        tile_map);
+    const unsigned nb = (unsigned)dd3d_conv_schedule_blocks(M_out);
+    if (dd3d_conv_schedule_tile_rows(M_out) == 128)
+        k_conv128_rows<4><<<dim3(nb), 256, 0, (hipStream_t)stream>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, 0, perm, tile_map);
+    else  // small launches: 32-row tiles (see dd3d_conv_fwd), same schedule machinery
+        k_conv128<32, 1, 4><<<dim3(nb), 256, 0, (hipStream_t)stream>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, 0, perm, tile_map);
     DD3D_CHECK_LAUNCH();
     return 0;
 }

@@ -121,12 +121,13 @@ __global__ __launch_bounds__(1024) void k_row_scatter(const unsigned* __restrict
 // offsets present in it (thread t folds the 128 patterns of tile t); the tiles are ranked by (cost descending, index) and rank i goes to
 // round i / 256, CU position i % 256 forwards in even rounds and backwards in odd ones.  More tiles than that are dispatched as slots
 // free up, where plain order is as good as any.
+template <int TR>  // rows per tile: 128 (k_conv128_rows) or 32 (k_conv128<32,1,4>)
 __global__ __launch_bounds__(1024) void k_tile_schedule(const unsigned* __restrict__ sorted_keys, int M_bound, const int* __restrict__ m_dev, int n_blocks,
                                                         int* __restrict__ tile_map) {
     __shared__ int s_cost[1024];
     const int tid = threadIdx.x;
     const int M = m_dev ? min(*m_dev, M_bound) : M_bound;
-    const int ntile = (M + 127) / 128;
+    const int ntile = (M + TR - 1) / TR;
     for (int b = tid; b < n_blocks; b += 1024) tile_map[b] = -1;
     __syncthreads();
     if (ntile > 1024) {
@@ -136,16 +137,16 @@ __global__ __launch_bounds__(1024) void k_tile_schedule(const unsigned* __restri
     int c = -1;
     if (tid < ntile) {
         unsigned u = 0;
-        const uint4* k4 = (const uint4*)(sorted_keys + (int64_t)tid * 128);   // 512-B aligned: the workspace carve is 256-B aligned
-        const int n = min(128, M - tid * 128);
-        if (n == 128) {  // 32 independent 16-B loads
-            uint4 q[32];
+        const uint4* k4 = (const uint4*)(sorted_keys + (int64_t)tid * TR);   // TR * 4 B aligned: the workspace carve is 256-B aligned
+        const int n = min(TR, M - tid * TR);
+        if (n == TR) {  // TR / 4 independent 16-B loads
+            uint4 q[TR / 4];
 #pragma unroll
-            for (int j = 0; j < 32; ++j) q[j] = k4[j];
+            for (int j = 0; j < TR / 4; ++j) q[j] = k4[j];
 #pragma unroll
-            for (int j = 0; j < 32; ++j) u |= q[j].x | q[j].y | q[j].z | q[j].w;
+            for (int j = 0; j < TR / 4; ++j) u |= q[j].x | q[j].y | q[j].z | q[j].w;
         } else {
-            for (int j = 0; j < n; ++j) u |= sorted_keys[(int64_t)tid * 128 + j];
+            for (int j = 0; j < n; ++j) u |= sorted_keys[(int64_t)tid * TR + j];
         }
         c = __popc(u);
     }
@@ -185,7 +186,11 @@ int64_t carve(int64_t M, void* ws, SchedWs* out) {
 
 }  // namespace
 
-DD3D_API int64_t dd3d_conv_schedule_blocks(int64_t M) { return ceil_div64(ceil_div64(M > 0 ? M : 1, 128), 256) * 256; }
+// rows per tile of a scheduled launch over M rows (M = the bound when a device-side count is used): the same rule picks the kernel in
+// dd3d_conv128_ordered
+DD3D_API int dd3d_conv_schedule_tile_rows(int64_t M) { return M >= 65536 ? 128 : 32; }
+
+DD3D_API int64_t dd3d_conv_schedule_blocks(int64_t M) { return ceil_div64(ceil_div64(M > 0 ? M : 1, dd3d_conv_schedule_tile_rows(M)), 256) * 256; }
 
 DD3D_API int64_t dd3d_conv_schedule_ws_bytes(int64_t M) { return carve(M, nullptr, nullptr); }
 
@@ -206,7 +211,10 @@ DD3D_API int dd3d_conv_schedule(const int32_t* nbr, int64_t ld, int K, int64_t M
     k_row_keys<<<dim3(nwg), 1024, 0, st>>>(nbr, ld, K, (int)M, m_dev, w.keys, w.hist);
     k_bucket_scan<<<1, 1024, 0, st>>>(w.hist);
     k_row_scatter<<<dim3(nwg), 1024, 0, st>>>(w.keys, (int)M, m_dev, w.hist, perm, w.sorted_keys);
-    k_tile_schedule<<<1, 1024, 0, st>>>(w.sorted_keys, (int)M, m_dev, (int)dd3d_conv_schedule_blocks(M), tile_map);
+    if (dd3d_conv_schedule_tile_rows(M) == 128)
+        k_tile_schedule<128><<<1, 1024, 0, st>>>(w.sorted_keys, (int)M, m_dev, (int)dd3d_conv_schedule_blocks(M), tile_map);
+    else
+        k_tile_schedule<32><<<1, 1024, 0, st>>>(w.sorted_keys, (int)M, m_dev, (int)dd3d_conv_schedule_blocks(M), tile_map);
     DD3D_CHECK_LAUNCH();
     return 0;
 }

@@ -108,7 +108,7 @@ class _Pass:
         # tile placement (dd3d_conv_schedule; results are bit-identical).  It needs the maps only, so it runs on the side stream next to
         # the first layer; its nodes are ENQUEUED after the first layer's (a HIP graph dispatches its nodes in capture order, and a
         # branch captured first holds back the one captured after it).
-        use_sched = M1 >= 65536 and os.environ.get("DD3D_CONV_SCHED", "1") != "0"
+        use_sched = M1 >= int(os.environ.get("DD3D_CONV_SCHED_MIN", "8192")) and os.environ.get("DD3D_CONV_SCHED", "1") != "0"
         self.sched = None
         if use_sched:
             ev_maps = torch.cuda.Event()

@@ -122,10 +122,11 @@ int dd3d_conv_fwd(const float* X, int64_t M_in, int Cin, const float* W, int Cou
 
 /* Launch schedule of the Cin = Cout = 128 convolution over one kernel map: perm[M] = the rows sorted (stable radix sort) by their K-bit
  * pattern of present offsets, so that the 32 rows one wave multiplies together share a pattern and absent offsets are skipped for the
- * whole block; tile_map[dd3d_conv_schedule_blocks(M)] = workgroup -> 128-row tile of that order (-1 = none), the tiles ranked by
+ * whole block; tile_map[dd3d_conv_schedule_blocks(M)] = workgroup -> tile (dd3d_conv_schedule_tile_rows(M) rows) of that order (-1 = none), the tiles ranked by
  * cost and dealt to the CUs in a snake so that the most loaded CU carries the average.  M is a bound when m_dev is given.  One
  * schedule serves the forward and the mirrored launch.  No counterpart in MinkowskiEngine (its gather-GEMM-scatter compacts per
  * offset instead); serves MEConv.py:224 like dd3d_conv_fwd. */
+int dd3d_conv_schedule_tile_rows(int64_t M); /* 128 from 65536 rows on (k_conv128_rows), 32 below (k_conv128<32,1,4>) */
 int64_t dd3d_conv_schedule_blocks(int64_t M);
 int64_t dd3d_conv_schedule_ws_bytes(int64_t M);
 int dd3d_conv_schedule(const int32_t* nbr, int64_t ld, int K, int64_t M, const int32_t* m_dev, int32_t* perm, int32_t* tile_map, void* ws,

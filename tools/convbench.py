@@ -47,15 +47,16 @@ for name, coords, B in (("real", b["coordinates"], 2560), ("syn", sc, 100), ("me
     sched(); run2(); torch.cuda.synchronize()
     assert sorted(perm.tolist()) == list(range(M)), "perm is not a permutation"
     tl = [t for t in tmap.tolist() if t >= 0]
-    assert sorted(tl) == list(range((M + 127) // 128)), "tile_map does not cover every tile once"
+    TR = int(L.lib.dd3d_conv_schedule_tile_rows(M))
+    assert sorted(tl) == list(range((M + TR - 1) // TR)), "tile_map does not cover every tile once"
     assert torch.equal(Y, Y2), "scheduled conv differs"
     present = nbr[:, :M] >= 0
     pm = present[:, perm.long()]
-    pm = torch.cat([pm, pm.new_zeros(27, (-M) % 128)], 1).reshape(27, -1, 128).any(2).sum(0).cpu() * 4
+    pm = torch.cat([pm, pm.new_zeros(27, (-M) % TR)], 1).reshape(27, -1, TR).any(2).sum(0).cpu() * 4
     loads = torch.zeros(256)
     for bi, t in enumerate(tmap.tolist()):
         if t >= 0: loads[bi % 256] += pm[t]
-    print(f"   schedule: tile-steps {int(pm.sum())} (cloud order {int(torch.cat([present, present.new_zeros(27, (-M) % 128)], 1).reshape(27, -1, 128).any(2).sum()) * 4}), most / least loaded CU {int(loads.max())} / {int(loads.min())}")
+    print(f"   schedule: tile-steps {int(pm.sum())} (cloud order {int(torch.cat([present, present.new_zeros(27, (-M) % TR)], 1).reshape(27, -1, TR).any(2).sum()) * 4}), most / least loaded CU {int(loads.max())} / {int(loads.min())}")
     for f, tag in ((sched, "dd3d_conv_schedule"), (run2, "scheduled conv")):
         e0.record()
         for _ in range(n): f()
