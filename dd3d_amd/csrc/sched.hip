@@ -124,7 +124,7 @@ __global__ __launch_bounds__(1024) void k_row_scatter(const unsigned* __restrict
 template <int TR>  // rows per tile: 128 (k_conv128_rows) or 32 (k_conv128<32,1,4>)
 __global__ __launch_bounds__(1024) void k_tile_schedule(const unsigned* __restrict__ sorted_keys, int M_bound, const int* __restrict__ m_dev, int n_blocks,
                                                         int* __restrict__ tile_map) {
-    __shared__ int s_cost[1024];
+    __shared__ __align__(16) int s_cost[1024];
     const int tid = threadIdx.x;
     const int M = m_dev ? min(*m_dev, M_bound) : M_bound;
     const int ntile = (M + TR - 1) / TR;
@@ -154,9 +154,14 @@ __global__ __launch_bounds__(1024) void k_tile_schedule(const unsigned* __restri
     __syncthreads();
     if (tid >= ntile) return;
     int rank = 0;
-    for (int u = 0; u < ntile; ++u) {
-        const int cu = s_cost[u];
-        rank += (cu > c) || (cu == c && u < tid);
+    const int4* s_cost4 = (const int4*)s_cost;   // slots beyond ntile hold -1: they never outrank a tile (cost >= 0)
+    for (int u4 = 0; u4 < (ntile + 3) / 4; ++u4) {
+        const int4 q = s_cost4[u4];
+        const int u = u4 * 4;
+        rank += (q.x > c) || (q.x == c && u < tid);
+        rank += (q.y > c) || (q.y == c && u + 1 < tid);
+        rank += (q.z > c) || (q.z == c && u + 2 < tid);
+        rank += (q.w > c) || (q.w == c && u + 3 < tid);
     }
     const int r = rank >> 8, pos = rank & 255;
     const int b = r * 256 + ((r & 1) ? 255 - pos : pos);
