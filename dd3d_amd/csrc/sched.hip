@@ -117,55 +117,66 @@ __global__ __launch_bounds__(1024) void k_row_scatter(const unsigned* __restrict
     }
 }
 
-// tile_map[b] = tile that workgroup b runs, or -1.  Up to 1024 tiles (every workgroup resident at once): a tile's cost is the number of
+// tile_map[b] = tile that workgroup b runs, or -1.  Up to 2048 tiles (every workgroup resident at once, or nearly): a tile's cost is the number of
 // offsets present in it (thread t folds the 128 patterns of tile t); the tiles are ranked by (cost descending, index) and rank i goes to
 // round i / 256, CU position i % 256 forwards in even rounds and backwards in odd ones.  More tiles than that are dispatched as slots
 // free up, where plain order is as good as any.
 template <int TR>  // rows per tile: 128 (k_conv128_rows) or 32 (k_conv128<32,1,4>)
 __global__ __launch_bounds__(1024) void k_tile_schedule(const unsigned* __restrict__ sorted_keys, int M_bound, const int* __restrict__ m_dev, int n_blocks,
                                                         int* __restrict__ tile_map) {
-    __shared__ __align__(16) int s_cost[1024];
+    constexpr int MAXT = 2048;  // two tiles per thread
+    __shared__ __align__(16) int s_cost[MAXT];
     const int tid = threadIdx.x;
     const int M = m_dev ? min(*m_dev, M_bound) : M_bound;
     const int ntile = (M + TR - 1) / TR;
     for (int b = tid; b < n_blocks; b += 1024) tile_map[b] = -1;
     __syncthreads();
-    if (ntile > 1024) {
+    if (ntile > MAXT) {
         for (int t = tid; t < ntile && t < n_blocks; t += 1024) tile_map[t] = t;
         return;
     }
-    int c = -1;
-    if (tid < ntile) {
-        unsigned u = 0;
-        const uint4* k4 = (const uint4*)(sorted_keys + (int64_t)tid * TR);   // TR * 4 B aligned: the workspace carve is 256-B aligned
-        const int n = min(TR, M - tid * TR);
-        if (n == TR) {  // TR / 4 independent 16-B loads
-            uint4 q[TR / 4];
+    int cost[2];
 #pragma unroll
-            for (int j = 0; j < TR / 4; ++j) q[j] = k4[j];
+    for (int j = 0; j < 2; ++j) {
+        const int t = tid + j * 1024;
+        int c = -1;
+        if (t < ntile) {
+            unsigned u = 0;
+            const uint4* k4 = (const uint4*)(sorted_keys + (int64_t)t * TR);   // TR * 4 B aligned: the workspace carve is 256-B aligned
+            const int n = min(TR, M - t * TR);
+            if (n == TR) {  // TR / 4 independent 16-B loads
+                uint4 q[TR / 4];
 #pragma unroll
-            for (int j = 0; j < TR / 4; ++j) u |= q[j].x | q[j].y | q[j].z | q[j].w;
-        } else {
-            for (int j = 0; j < n; ++j) u |= sorted_keys[(int64_t)tid * TR + j];
+                for (int i = 0; i < TR / 4; ++i) q[i] = k4[i];
+#pragma unroll
+                for (int i = 0; i < TR / 4; ++i) u |= q[i].x | q[i].y | q[i].z | q[i].w;
+            } else {
+                for (int i = 0; i < n; ++i) u |= sorted_keys[(int64_t)t * TR + i];
+            }
+            c = __popc(u);
         }
-        c = __popc(u);
+        cost[j] = c;
+        s_cost[t] = c;
     }
-    s_cost[tid] = c;
     __syncthreads();
-    if (tid >= ntile) return;
-    int rank = 0;
     const int4* s_cost4 = (const int4*)s_cost;   // slots beyond ntile hold -1: they never outrank a tile (cost >= 0)
-    for (int u4 = 0; u4 < (ntile + 3) / 4; ++u4) {
-        const int4 q = s_cost4[u4];
-        const int u = u4 * 4;
-        rank += (q.x > c) || (q.x == c && u < tid);
-        rank += (q.y > c) || (q.y == c && u + 1 < tid);
-        rank += (q.z > c) || (q.z == c && u + 2 < tid);
-        rank += (q.w > c) || (q.w == c && u + 3 < tid);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int t = tid + j * 1024, c = cost[j];
+        if (t >= ntile) continue;
+        int rank = 0;
+        for (int u4 = 0; u4 < (ntile + 3) / 4; ++u4) {
+            const int4 q = s_cost4[u4];
+            const int u = u4 * 4;
+            rank += (q.x > c) || (q.x == c && u < t);
+            rank += (q.y > c) || (q.y == c && u + 1 < t);
+            rank += (q.z > c) || (q.z == c && u + 2 < t);
+            rank += (q.w > c) || (q.w == c && u + 3 < t);
+        }
+        const int r = rank >> 8, pos = rank & 255;
+        const int b = r * 256 + ((r & 1) ? 255 - pos : pos);
+        if (b < n_blocks) tile_map[b] = t;
     }
-    const int r = rank >> 8, pos = rank & 255;
-    const int b = r * 256 + ((r & 1) ? 255 - pos : pos);
-    if (b < n_blocks) tile_map[b] = tid;
 }
 
 struct SchedWs {
