@@ -198,19 +198,9 @@ __global__ __launch_bounds__(RL * 32) void k_inorm_bwd(const f32x4* __restrict__
 }
 
 // ---- fused affine + ReLU + max-pool (k=2, s=2) ------------------------------------------------
-// out[o][c] = max over existing children i of relu(xhat[i][c]*w[c]+b[c]); first maximum in offset order wins; arg = child row
-__global__ __launch_bounds__(256) void k_arp_fwd(const f32x4* __restrict__ xhat, const f32x4* __restrict__ w, const f32x4* __restrict__ bias,
-                                                 int use_affine_relu, const int* __restrict__ kids, int64_t ld, int Kp, int64_t M_bound,
-                                                 const int* __restrict__ m_dev, f32x4* __restrict__ out, int4* __restrict__ arg) {
-    const int c4 = threadIdx.x & 31;
-    int64_t o = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
-    const int64_t M_out = m_dev ? min((int64_t)*m_dev, M_bound) : M_bound;
-    if (o >= M_out) return;
-    f32x4 ww = {1.f, 1.f, 1.f, 1.f}, bb = {0.f, 0.f, 0.f, 0.f};
-    if (use_affine_relu) {
-        ww = w[c4];
-        bb = bias[c4];
-    }
+// one pooled row x one float4 channel lane of k_arp_fwd (shared with the fused instance-norm kernel)
+__device__ __forceinline__ void arp_row(const f32x4* __restrict__ xhat, const int* __restrict__ kids, int64_t ld, int Kp, int64_t o, int c4, f32x4 ww,
+                                        f32x4 bb, int use_affine_relu, f32x4* __restrict__ out, int4* __restrict__ arg) {
     const float ninf = -__builtin_inff();
     f32x4 best = {ninf, ninf, ninf, ninf};
     int4 a = make_int4(-1, -1, -1, -1);
@@ -240,6 +230,78 @@ __global__ __launch_bounds__(256) void k_arp_fwd(const f32x4* __restrict__ xhat,
     out[o * 32 + c4] = best;
     arg[o * 32 + c4] = a;
 }
+
+// out[o][c] = max over existing children i of relu(xhat[i][c]*w[c]+b[c]); first maximum in offset order wins; arg = child row
+__global__ __launch_bounds__(256) void k_arp_fwd(const f32x4* __restrict__ xhat, const f32x4* __restrict__ w, const f32x4* __restrict__ bias,
+                                                 int use_affine_relu, const int* __restrict__ kids, int64_t ld, int Kp, int64_t M_bound,
+                                                 const int* __restrict__ m_dev, f32x4* __restrict__ out, int4* __restrict__ arg) {
+    const int c4 = threadIdx.x & 31;
+    int64_t o = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int64_t M_out = m_dev ? min((int64_t)*m_dev, M_bound) : M_bound;
+    if (o >= M_out) return;
+    f32x4 ww = {1.f, 1.f, 1.f, 1.f}, bb = {0.f, 0.f, 0.f, 0.f};
+    if (use_affine_relu) {
+        ww = w[c4];
+        bb = bias[c4];
+    }
+    arp_row(xhat, kids, ld, Kp, o, c4, ww, bb, use_affine_relu, out, arg);
+}
+
+// Instance norm forward + affine + ReLU + max-pool in one launch per level (one workgroup per cloud).
+template <int RL, int CACHE>
+__global__ __launch_bounds__(RL * 32) void k_inorm_arp_fwd(const f32x4* __restrict__ Y, const int* __restrict__ seg_off, f32x4* __restrict__ xhat,
+                                                           f32x4* __restrict__ inv_std, const f32x4* __restrict__ w, const f32x4* __restrict__ bias,
+                                                           const int* __restrict__ kids, int64_t ld, int Kp, const int* __restrict__ seg_out,
+                                                           f32x4* __restrict__ pooled, int4* __restrict__ arg) {
+    __shared__ f32x4 s_red[RL * 32];
+    const int b = blockIdx.x, c4 = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int r0 = seg_off[b], r1 = seg_off[b + 1];
+    const int n = r1 - r0;
+    if (n <= 0) {  // a cloud without voxels has no pooled rows either
+        if (rl == 0) inv_std[(int64_t)b * 32 + c4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        return;
+    }
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 v[CACHE];
+    f32x4 s = zero;
+#pragma unroll
+    for (int i = 0; i < CACHE; ++i) {  // clamped row index: branch-free, all CACHE loads in flight together
+        int r = r0 + rl + i * RL;
+        v[i] = Y[(int64_t)min(r, r1 - 1) * 32 + c4];
+        if (r >= r1) v[i] = zero;
+        s += v[i];
+    }
+    for (int r = r0 + rl + CACHE * RL; r < r1; r += RL) s += Y[(int64_t)r * 32 + c4];
+    const f32x4 mean = cloud_colsum<RL>(s, s_red) / (float)n;
+    f32x4 q = zero;
+#pragma unroll
+    for (int i = 0; i < CACHE; ++i) {
+        int r = r0 + rl + i * RL;
+        f32x4 d = v[i] - mean;
+        if (r < r1) q += d * d;
+    }
+    for (int r = r0 + rl + CACHE * RL; r < r1; r += RL) {
+        f32x4 d = Y[(int64_t)r * 32 + c4] - mean;
+        q += d * d;
+    }
+    const f32x4 var = cloud_colsum<RL>(q, s_red) / (float)n;
+    f32x4 is;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) is[j] = 1.0f / sqrtf(var[j] + 1e-8f);
+    if (rl == 0) inv_std[(int64_t)b * 32 + c4] = is;
+#pragma unroll
+    for (int i = 0; i < CACHE; ++i) {
+        int r = r0 + rl + i * RL;
+        if (r < r1) xhat[(int64_t)r * 32 + c4] = (v[i] - mean) * is;
+    }
+    for (int r = r0 + rl + CACHE * RL; r < r1; r += RL) xhat[(int64_t)r * 32 + c4] = (Y[(int64_t)r * 32 + c4] - mean) * is;
+    // affine + ReLU + max-pool of THIS cloud's pooled rows: their children are rows of this cloud, just written by this workgroup
+    // (the barrier makes them visible to it), so they come back from L2 / L1 instead of a second pass over HBM in another launch
+    __syncthreads();
+    const f32x4 ww = w[c4], bb = bias[c4];
+    for (int64_t o = seg_out[b] + rl; o < seg_out[b + 1]; o += RL) arp_row(xhat, kids, ld, Kp, o, c4, ww, bb, 1, pooled, arg);
+}
+
 
 // Backward of pool -> ReLU -> affine for every INPUT row i (each has exactly one parent):
 //   gy = (arg[parent[i]] == i) ? g_pool[parent[i]] : 0 ; ga = (xhat*w+b > 0) ? gy : 0 ; g_xhat = ga * w
@@ -499,6 +561,19 @@ DD3D_API int dd3d_affine_relu_pool_fwd(const float* xhat, const float* w, const 
     if (!xhat || !kids || !out || !arg) return DD3D_EARG;
     k_arp_fwd<<<dim3((unsigned)ceil_div64(M_out, 8)), 256, 0, (hipStream_t)stream>>>((const f32x4*)xhat, (const f32x4*)w, (const f32x4*)b, use_affine_relu,
                                                                                     kids, ld, Kp, M_out, m_dev, (f32x4*)out, (int4*)arg);
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}
+
+// dd3d_inorm_fwd followed by dd3d_affine_relu_pool_fwd (affine + ReLU on) in one launch: same xhat / inv_std / pooled / arg, bit for bit.
+// seg_out[B+1]: the clouds' row ranges at the pooled level (a cloud's pooled rows only have children in that cloud).
+DD3D_API int dd3d_inorm_arp_fwd(const float* Y, const int32_t* seg_off, int B, int C, float* xhat, float* inv_std, const float* w, const float* b,
+                                const int32_t* kids, int64_t ld, int Kp, const int32_t* seg_out, float* pooled, int32_t* arg, void* stream) {
+    if (B < 0 || C != 128 || Kp <= 0 || Kp > 8) return DD3D_EARG;
+    if (B == 0) return 0;
+    if (!Y || !seg_off || !xhat || !inv_std || !w || !b || !kids || !seg_out || !pooled || !arg) return DD3D_EARG;
+    k_inorm_arp_fwd<16, 8><<<dim3(B), 512, 0, (hipStream_t)stream>>>((const f32x4*)Y, seg_off, (f32x4*)xhat, (f32x4*)inv_std, (const f32x4*)w, (const f32x4*)b,
+                                                                     kids, ld, Kp, seg_out, (f32x4*)pooled, (int4*)arg);
     DD3D_CHECK_LAUNCH();
     return 0;
 }

@@ -121,9 +121,10 @@ class _Pass:
         Y0 = _empty((M0, 128), dev)
         L.call("dd3d_conv_fwd", L.ptr(F0), M0, 3, L.ptr(W0), 128, L.ptr(k0), ld0, 27, M0, c0, 0, L.ptr(Y0), st)
         xh0, is0 = self.xh0, self.is0 = _empty((M0, 128), dev), _empty((B, 128), dev)
-        L.call("dd3d_inorm_fwd", L.ptr(Y0), L.ptr(seg1), B, 128, L.ptr(xh0), L.ptr(is0), st)
         P0, arg0 = self.P0, self.arg0 = _empty((M1, 128), dev), _empty((M1, 128), dev, _I32)
-        L.call("dd3d_affine_relu_pool_fwd", L.ptr(xh0), L.ptr(w1), L.ptr(b1), 1, 128, L.ptr(p0), pl0, 8, M1, c1, L.ptr(P0), L.ptr(arg0), st)
+        # instance norm + affine + ReLU + max-pool of a level in one launch per cloud (the pooled rows re-read their children from cache)
+        L.call("dd3d_inorm_arp_fwd", L.ptr(Y0), L.ptr(seg1), B, 128, L.ptr(xh0), L.ptr(is0), L.ptr(w1), L.ptr(b1), L.ptr(p0), pl0, 8, L.ptr(seg2),
+               L.ptr(P0), L.ptr(arg0), st)
         Y1 = _empty((M1, 128), dev)
         if use_sched:
             perm1 = _empty((M1,), dev, _I32)
@@ -139,9 +140,9 @@ class _Pass:
         else:
             L.call("dd3d_conv_fwd", L.ptr(P0), M1, 128, L.ptr(W1), 128, L.ptr(k1), ld1, 27, M1, c1, 0, L.ptr(Y1), st)
         xh1, is1 = self.xh1, self.is1 = _empty((M1, 128), dev), _empty((B, 128), dev)
-        L.call("dd3d_inorm_fwd", L.ptr(Y1), L.ptr(seg2), B, 128, L.ptr(xh1), L.ptr(is1), st)
         P1, arg1 = self.P1, self.arg1 = _empty((M2, 128), dev), _empty((M2, 128), dev, _I32)
-        L.call("dd3d_affine_relu_pool_fwd", L.ptr(xh1), L.ptr(w5), L.ptr(b5), 1, 128, L.ptr(p1), pl1, 8, M2, c2, L.ptr(P1), L.ptr(arg1), st)
+        L.call("dd3d_inorm_arp_fwd", L.ptr(Y1), L.ptr(seg2), B, 128, L.ptr(xh1), L.ptr(is1), L.ptr(w5), L.ptr(b5), L.ptr(p1), pl1, 8,
+               L.ptr(dp.seg_off), L.ptr(P1), L.ptr(arg1), st)
         logits = self.logits = _empty((B, J), dev)
         sl_fwd_call(P1, dp, None, Wsm, sst, J, cls_b, logits)
         prob, dl = self.prob, self.dl = _empty((B, J), dev), _empty((B, J), dev)

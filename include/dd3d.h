@@ -172,6 +172,12 @@ int dd3d_inorm_bwd(const float* g, const float* xhat, const float* inv_std, cons
 int dd3d_affine_relu_pool_fwd(const float* xhat, const float* w, const float* b, int use_affine_relu, int C, const int32_t* kids, int64_t ld,
                               int Kp, int64_t M_out, const int32_t* m_dev, float* out, int32_t* arg, void* stream);
 
+/* dd3d_inorm_fwd + dd3d_affine_relu_pool_fwd (affine + ReLU on) in one launch, one workgroup per cloud: identical outputs; the pooled
+ * level re-reads its children from cache instead of HBM.  seg_out[B+1] = the clouds' row ranges at the pooled level.
+ * replaces: MinkowskiInstanceNorm + MinkowskiReLU + MinkowskiMaxPooling forward, models/MEConv.py:225-227 */
+int dd3d_inorm_arp_fwd(const float* Y, const int32_t* seg_off, int B, int C, float* xhat, float* inv_std, const float* w, const float* b,
+                       const int32_t* kids, int64_t ld, int Kp, const int32_t* seg_out, float* pooled, int32_t* arg, void* stream);
+
 /* backward of the same three ops for every input row; gw_w/gw_b[G,C] are the per-group affine gradients (nullable pair);
  * ga_out (nullable) keeps the ReLU-masked pooled gradient; ga_prev + gw_extra[G,C] (nullable pair) add ga_prev*gw_extra[group]. */
 int64_t dd3d_arp_bwd_ws_bytes(int64_t M_in, int G);

@@ -278,6 +278,34 @@ def test_fused_norm_act_pool_first_and_second_order(case):
     assert rel_err(g2, r2) < 5e-5
 
 
+@pytest.mark.parametrize("case", CASES + [dict(B=4, pts=2500, extent=28, seed=8, dims3=True)])
+def test_one_launch_norm_act_pool_is_bitwise_the_two_launches(case):
+    """dd3d_inorm_arp_fwd == dd3d_inorm_fwd followed by dd3d_affine_relu_pool_fwd, bit for bit (clouds larger than the LDS cache too)."""
+    from dd3d_amd import _lib as L
+    coords = make_coords(**case)
+    cm = manager(coords)
+    M, Mo, B = cm.num_rows(1), cm.num_rows(2), cm.B
+    kids, ld = cm.kernel_map(1, 2, 2)
+    g = torch.Generator().manual_seed(9)
+    Y = (torch.randn(M, 128, generator=g) * 2 - 0.5).to(dev())
+    w = (1 + 0.2 * torch.randn(128, generator=g)).to(dev())
+    b = (0.2 * torch.randn(128, generator=g)).to(dev())
+    st = L.stream()
+
+    def bufs():
+        return (torch.full((M, 128), 7.0, device=dev()), torch.full((B, 128), 7.0, device=dev()), torch.full((Mo, 128), 7.0, device=dev()),
+                torch.full((Mo, 128), -3, device=dev(), dtype=torch.int32))
+    xa, ia, pa, aa = bufs()
+    L.call("dd3d_inorm_fwd", L.ptr(Y), L.ptr(cm.seg_off(1)), B, 128, L.ptr(xa), L.ptr(ia), st)
+    L.call("dd3d_affine_relu_pool_fwd", L.ptr(xa), L.ptr(w), L.ptr(b), 1, 128, L.ptr(kids), ld, 8, Mo, None, L.ptr(pa), L.ptr(aa), st)
+    xb, ib, pb, ab = bufs()
+    L.call("dd3d_inorm_arp_fwd", L.ptr(Y), L.ptr(cm.seg_off(1)), B, 128, L.ptr(xb), L.ptr(ib), L.ptr(w), L.ptr(b), L.ptr(kids), ld, 8,
+           L.ptr(cm.seg_off(2)), L.ptr(pb), L.ptr(ab), st)
+    torch.cuda.synchronize()
+    for u, v in ((xa, xb), (ia, ib), (pa, pb), (aa, ab)):
+        assert torch.equal(u, v)
+
+
 def test_sparse_linear_closed_under_differentiation():
     from dd3d_amd.ops import DensePlacement, sparse_linear
     coords = make_coords(B=6, pts=200, extent=28, seed=6)
