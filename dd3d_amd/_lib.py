@@ -53,6 +53,8 @@ _SIGS = {
     "dd3d_conv_schedule_ws_bytes": (I64, [I64]),
     "dd3d_conv_schedule": (I32, [P, I64, I32, I64, P, P, P, P, I64, P]),
     "dd3d_conv128_ordered": (I32, [P, I64, P, P, I64, I32, I64, P, I32, P, P, P, P]),
+    "dd3d_conv128_split_ws_bytes": (I64, [I64]),
+    "dd3d_conv128_split": (I32, [P, I64, P, P, I64, I32, I64, P, I32, P, P, I64, P]),
     "dd3d_conv_bwd_data": (I32, [P, I64, P, I32, P, I32, P, I64, I32, P, P]),
     "dd3d_conv_bwd_weight_ws_bytes": (I64, [I64, I32, I32, I32, I32]),
     "dd3d_conv_bwd_weight": (I32, [P, I32, P, I32, P, I64, I32, I64, P, I32, P, P, I64, P]),

@@ -34,10 +34,21 @@ inline int64_t max_slots128(int64_t bound, int G) { return ceil_div64(bound, 128
 // ---------------------------------------------------------------------------------------------
 // Cin = Cout = 128 forward / backward-data
 // ---------------------------------------------------------------------------------------------
-template <int TM, int WAVES_M, int WAVES_N>
+// Offsets-split launches (SPLIT): a launch with few tiles (the synthetic rows of the second-order pass: ~100 tiles for 256 CUs, each
+// a serial chain of 108 steps) is dealt over blockIdx.y = S workgroups per tile, each taking a contiguous range of the K offsets and
+// writing its partial tile to part[s][M_bound][128]; k_split_sum adds the partials in split order.  S follows the TRUE tile count.
+__host__ __device__ __forceinline__ int split_count(int ntile, int smax) {
+    // <= 56 tiles: 9 splits of 3 offsets; from ~170 tiles on the tiles alone keep the matrix cores of every CU busy (measured: 250 tiles
+    // take 57 us split nine ways plus 8 us of summing against 60 us unsplit) and the launch runs unsplit, straight into Y
+    const int s = 512 / (ntile > 0 ? ntile : 1);
+    return s < 3 ? 1 : (s > smax ? smax : s);
+}
+
+template <int TM, int WAVES_M, int WAVES_N, bool SPLIT = false>
 __global__ __launch_bounds__(256) void k_conv128(const float* __restrict__ X, const float* __restrict__ W, const int* __restrict__ nbr, int64_t ld,
                                                  int K, int M_bound, const int* __restrict__ m_dev, int mirror, float* __restrict__ Y, int xcd_remap,
-                                                 const int* __restrict__ perm = nullptr, const int* __restrict__ tile_map = nullptr) {
+                                                 const int* __restrict__ perm = nullptr, const int* __restrict__ tile_map = nullptr,
+                                                 float* __restrict__ part = nullptr, int smax = 1) {
     constexpr int BK = 32, LDA4 = 9 /* (BK+4)/4 float4 per A row: +16 B pad keeps ds_read_b128 conflict-free */;
     constexpr int WM = TM / WAVES_M, WN = 128 / WAVES_N, MT = WM / 32, NT = WN / 32;
     static_assert(WAVES_M * WAVES_N == 4 && MT >= 1 && NT >= 1, "4 waves");
@@ -61,6 +72,13 @@ __global__ __launch_bounds__(256) void k_conv128(const float* __restrict__ X, co
     }
     const int64_t row0 = (int64_t)tile * TM;
     if (tile >= ntile || (!tile_map && xcd_remap && (int)(blockIdx.x >> 3) >= per_xcd)) return;
+    int ks0 = 0, ks1 = K, S = 1;  // this workgroup's offsets
+    if (SPLIT) {
+        S = split_count(ntile, smax);
+        if ((int)blockIdx.y >= S) return;
+        ks0 = K * (int)blockIdx.y / S;
+        ks1 = K * ((int)blockIdx.y + 1) / S;
+    }
 
     if (tid == 0) s_kmask = 0;
     if (tid < TM) {
@@ -73,7 +91,7 @@ __global__ __launch_bounds__(256) void k_conv128(const float* __restrict__ X, co
         int k = idx / TM, r = idx - k * TM;
         const int row = s_row[r];
         int ks = mirror ? K - 1 - k : k;
-        int v = row < M_out ? nbr[(int64_t)ks * ld + row] : -1;
+        int v = (row < M_out && (!SPLIT || (k >= ks0 && k < ks1))) ? nbr[(int64_t)ks * ld + row] : -1;
         s_nbr[idx] = v;
         if (v >= 0) mymask |= 1u << k;
     }
@@ -175,8 +193,26 @@ __global__ __launch_bounds__(256) void k_conv128(const float* __restrict__ X, co
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t row = s_row[wrow0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
-                if (row < M_out) Y[row * 128 + wcol0 + n * 32 + i32] = acc[m][n][r];
+                float* out = S > 1 ? part + (int64_t)blockIdx.y * M_bound * 128 : Y;
+                if (row < M_out) out[row * 128 + wcol0 + n * 32 + i32] = acc[m][n][r];
             }
+}
+
+// Y[row] = part[0][row] + part[1][row] + ... in split order (all nine loads of a lane in flight); 8 rows per workgroup
+__global__ __launch_bounds__(256) void k_split_sum(const f32x4* __restrict__ part, int M_bound, const int* __restrict__ m_dev, int smax, f32x4* __restrict__ Y) {
+    const int M_out = m_dev ? min(*m_dev, M_bound) : M_bound;
+    const int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (row >= M_out) return;
+    const int S = split_count((M_out + 31) / 32, smax), c4 = threadIdx.x & 31;
+    if (S == 1) return;  // the tiles went straight into Y
+    f32x4 v[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) v[q] = part[((int64_t)min(q, S - 1) * M_bound + row) * 32 + c4];
+    f32x4 t = v[0];
+#pragma unroll
+    for (int q = 1; q < 9; ++q)
+        if (q < S) t += v[q];
+    Y[row * 32 + c4] = t;
 }
 
 // Row-private variant for large launches: wave w of the workgroup owns output rows [32w, 32w+32) of the tile and ALL 128 columns
@@ -819,6 +855,25 @@ DD3D_API int dd3d_conv128_ordered(const float* X, int64_t M_in, const float* W, 
         k_conv128_rows<4><<<dim3(nb), 256, 0, (hipStream_t)stream>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, 0, perm, tile_map);
     else  // small launches: 32-row tiles (see dd3d_conv_fwd), same schedule machinery
         k_conv128<32, 1, 4><<<dim3(nb), 256, 0, (hipStream_t)stream>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, 0, perm, tile_map);
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}
+
+// dd3d_conv_fwd for Cin = Cout = 128 with the offsets of every tile dealt over up to 9 workgroups (launches of few rows, which would
+// leave most CUs idle behind a serial chain per tile); ws holds the partial tiles.  Deterministic; the sum over the offsets is
+// associated per split, so the result equals dd3d_conv_fwd's to fp32 rounding, not bit for bit.
+DD3D_API int64_t dd3d_conv128_split_ws_bytes(int64_t M_out) { return 9 * (M_out > 0 ? M_out : 1) * 128 * (int64_t)sizeof(float); }
+DD3D_API int dd3d_conv128_split(const float* X, int64_t M_in, const float* W, const int32_t* nbr, int64_t ld, int K, int64_t M_out, const int32_t* m_dev,
+                                int mirror, float* Y, void* ws, int64_t ws_bytes, void* stream) {
+    if (M_out < 0 || M_in < 0 || K != 27 || ld < M_out) return DD3D_EARG;
+    if (M_out >= (1ll << 31) / 128 * 16 / 9) return DD3D_ESIZE;
+    if (M_out == 0) return 0;
+    if (!X || !W || !nbr || !Y) return DD3D_EARG;
+    if (!ws || ws_bytes < dd3d_conv128_split_ws_bytes(M_out)) return DD3D_EWS;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nt = ceil_div64(M_out, 32);
+    k_conv128<32, 1, 4, true><<<dim3((unsigned)nt, 9), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, 0, nullptr, nullptr, (float*)ws, 9);
+    k_split_sum<<<dim3((unsigned)ceil_div64(M_out, 8)), 256, 0, st>>>((const f32x4*)ws, (int)M_out, m_dev, 9, (f32x4*)Y);
     DD3D_CHECK_LAUNCH();
     return 0;
 }

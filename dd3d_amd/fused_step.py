@@ -30,6 +30,9 @@ from .ops import DensePlacement, _site_strides, site_major, sl_bwd_x_call, sl_fw
 from .sparse import CloudCoordinateManager, CoordinateManager
 from .utils.Mnist2D import batch_from_images
 
+# row bound up to which the second-order 128-channel convolution (synthetic rows only) runs offsets-split (dd3d_conv128_split)
+SPLIT_MAX_ROWS = int(os.environ.get("DD3D_CONV_SPLIT_MAX", "65536"))
+
 _F32, _I32 = torch.float32, torch.int32
 
 
@@ -232,7 +235,11 @@ class _Pass:
         sl_bwd_x_call(dz, dp, None, self.Wsm, sst, J, 1, H, Bs, Ns)
         hY1, _, _ = self._arp_inorm_bwd(H, self.arg1, cm.parent(4), self.xh1, self.is1, w5, b5, seg2, Ns, Bs, Gs, None, 0, False, self.ga1, G_w5)
         hP0 = _empty((Ns, 128), dev)
-        L.call("dd3d_conv_bwd_data", L.ptr(hY1), Ns, m2s, 128, L.ptr(self.W1t), 128, L.ptr(k1), ld1, 27, L.ptr(hP0), st)
+        if Ns <= SPLIT_MAX_ROWS:  # few tiles: deal every tile's offsets over several CUs
+            ws = L.workspace(int(L.lib.dd3d_conv128_split_ws_bytes(Ns)), dev)
+            L.call("dd3d_conv128_split", L.ptr(hY1), Ns, L.ptr(self.W1t), L.ptr(k1), ld1, 27, Ns, m2s, 1, L.ptr(hP0), L.ptr(ws), ws.numel(), st)
+        else:
+            L.call("dd3d_conv_bwd_data", L.ptr(hY1), Ns, m2s, 128, L.ptr(self.W1t), 128, L.ptr(k1), ld1, 27, L.ptr(hP0), st)
         hY0, _, _ = self._arp_inorm_bwd(hP0, self.arg0, cm.parent(2), self.xh0, self.is0, w1, b1, seg1, Ns, Bs, Gs, None, 0, False, self.ga0, G_w1)
         hF0 = _empty((Ns, 3), dev)
         L.call("dd3d_conv_bwd_data", L.ptr(hY0), Ns, m1s, 128, L.ptr(W0), 3, L.ptr(k0), ld0, 27, L.ptr(hF0), st)

@@ -138,6 +138,14 @@ int dd3d_conv_schedule(const int32_t* nbr, int64_t ld, int K, int64_t M, const i
 int dd3d_conv128_ordered(const float* X, int64_t M_in, const float* W, const int32_t* nbr, int64_t ld, int K, int64_t M_out, const int32_t* m_dev,
                          int mirror, const int32_t* perm, const int32_t* tile_map, float* Y, void* stream);
 
+/* dd3d_conv_fwd for Cin = Cout = 128, K = 27 for launches of few rows (the synthetic rows of the second-order pass): the offsets of
+ * every 32-row tile are dealt over up to nine workgroups (count chosen from the true row count), partial tiles go to ws and are added
+ * in split order.  Deterministic; equals dd3d_conv_fwd to fp32 rounding (the sum over offsets is associated per split), not bit for bit.
+ * replaces: ConvolutionForwardGPU / ConvolutionBackwardGPU (input gradient, mirror = 1 with the transposed kernel), MEConv.py:224 */
+int64_t dd3d_conv128_split_ws_bytes(int64_t M_out);
+int dd3d_conv128_split(const float* X, int64_t M_in, const float* W, const int32_t* nbr, int64_t ld, int K, int64_t M_out, const int32_t* m_dev,
+                       int mirror, float* Y, void* ws, int64_t ws_bytes, void* stream);
+
 /* dX[M,Cin] of a stride-1 convolution.  Cin = 128: pass the transposed kernel [K,Cout,Cin]; Cin = 3: pass W itself.
  * replaces: ConvolutionBackwardGPU (input gradient) reached by torch.autograd.grad / loss.backward, mnist_distill.py:349,359,365 */
 int dd3d_conv_bwd_data(const float* dY, int64_t M, const int32_t* m_dev, int Cout, const float* W_or_Wt, int Cin, const int32_t* nbr, int64_t ld,

@@ -457,3 +457,42 @@ def test_scheduled_conv128_is_bit_identical(M, bound):
         pm = torch.cat([pm, pm.new_zeros(27, (-M) % 32)], 1)
         return int(pm.reshape(27, -1, 32).any(2).sum())
     assert M < 64 or blocks(perm[:M]) < blocks(torch.arange(M, device=d))
+
+
+@pytest.mark.parametrize("M,bound,mirror", [(1, 1, 0), (31, 40, 1), (1600, 1600, 0), (3500, 20000, 1), (5000, 5000, 1), (9000, 9000, 0), (20000, 20000, 1), (80000, 80000, 0)])
+def test_offsets_split_conv128_matches_plain_and_oracle(M, bound, mirror):
+    """dd3d_conv128_split (every split count from 9 down to 1) against dd3d_conv_fwd (fp32 rounding apart) and, for the small cases, the fp64 oracle;
+    rows beyond the device-side count stay untouched; two calls give the same bits."""
+    from dd3d_amd import _lib as L
+    g = torch.Generator().manual_seed(M + mirror)
+    nbr = torch.randint(0, M, (27, bound), generator=g, dtype=torch.int32)
+    nbr[torch.rand(27, bound, generator=g) > 0.3] = -1
+    nbr[13, :M] = torch.arange(M, dtype=torch.int32)
+    X = torch.randn(M, 128, generator=g)
+    W = torch.randn(27, 128, 128, generator=g) * 0.05
+    nbr_d, X_d, W_d = nbr.to(dev()), X.to(dev()), W.to(dev())
+    m_dev = torch.tensor([M], dtype=torch.int32, device=dev()) if bound != M else None
+    st = L.stream()
+    Y0 = torch.full((bound, 128), 7.0, device=dev())
+    L.call("dd3d_conv_fwd", L.ptr(X_d), M, 128, L.ptr(W_d), 128, L.ptr(nbr_d), bound, 27, bound, L.ptr(m_dev) if m_dev is not None else None, mirror, L.ptr(Y0), st)
+    ws = torch.empty(int(L.lib.dd3d_conv128_split_ws_bytes(bound)), dtype=torch.uint8, device=dev())
+    outs = []
+    for _ in range(2):
+        ws.fill_(0xFF)  # NaN bit patterns: every partial that is read must have been written by this call
+        Y = torch.full((bound, 128), 7.0, device=dev())
+        L.call("dd3d_conv128_split", L.ptr(X_d), M, L.ptr(W_d), L.ptr(nbr_d), bound, 27, bound, L.ptr(m_dev) if m_dev is not None else None, mirror, L.ptr(Y),
+               L.ptr(ws), ws.numel(), st)
+        outs.append(Y)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0][M:], Y0[M:])
+    assert rel_err(outs[0][:M], Y0[:M]) < 2e-6
+    if M <= 9000:
+        ref = torch.zeros(M, 128, dtype=torch.float64)
+        Xd, Wd = X.double(), W.double()
+        for k in range(27):
+            idx = nbr[26 - k if mirror else k, :M].long()
+            has = idx >= 0
+            ref[has] += Xd[idx[has]] @ Wd[k]
+        assert rel_err(outs[0][:M], ref) < 2e-5
+    assert L.lib.dd3d_conv128_split(L.ptr(X_d), M, L.ptr(W_d), L.ptr(nbr_d), bound, 27, bound, None, 0, L.ptr(outs[0]), L.ptr(ws), 16, st) == -3
