@@ -1,6 +1,6 @@
 """Benchmark of the gradient-matching outer step (BASELINE.json metric) on MI355X.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 100 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One step = mnist_distill.py:309-374 without evaluation / logging / export: all classes, real + synthetic forward/backward,
@@ -53,8 +53,8 @@ class KernelTimer:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--ipc", type=int, default=IPC)
     ap.add_argument("--metric-name", default="modmse", help="dist_opt: modmse (INI default) | ours | mse | cos")
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4"],
