@@ -185,6 +185,20 @@ def main():
         if args.path != "dropin" and args.config == "cfg2" and args.ipc == IPC and os.path.exists(pmc):
             roof["traffic"] = json.load(open(pmc))["traffic_bytes_per_launch"]
             roof["traffic_source"] = "profiles/r01_pmc_conv128_rows.json"
+        step_work = None
+        if args.path != "dropin":
+            # the counts the algorithmic work of a step follows from (merged batch of the last step of this rank) and the
+            # whole-step rates: conv0 / conv1 / classifier each run forward, backward-data and backward-weight over the merged batch
+            # (the second-order pass over the synthetic prefix adds < 4 % and is left out)
+            ps = d.last["passes"][0]
+            M0, M1, M2 = d.row_counts()[0]
+            P0 = int((ps.maps[0][:, :M0] >= 0).sum().item())
+            P1 = int((ps.maps[4][:, :M1] >= 0).sum().item())
+            ncls = len(d.classes)
+            flop = 3 * (2.0 * P0 * 3 * 128 + 2.0 * P1 * 128 * 128 + 2.0 * M2 * 128 * n_classes)
+            step_s = dt / args.steps
+            step_work = {"N_bound": int(ps.N), "M0": M0, "M1": M1, "M2": M2, "P0": P0, "P1": P1, "classes_on_rank": ncls, "flop_algorithmic": flop,
+                         "formula": "3*(2*P0*3*128 + 2*P1*128*128 + 2*M2*128*n_cls)", "tflops_whole_step": flop / step_s / 1e12}
         out = {"metric": METRIC, "value": args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
                "data": "synthetic", "config": {"workload": (f"{args.config}: MNIST-3D-shaped stroke digits, {NUM_CLASSES} classes x {REAL_PER_CLASS} real clouds, "
@@ -194,7 +208,7 @@ def main():
                                                "parallelism": f"class-sharded x{world}",
                                                "path": {"graph": "class-batched step, one HIP graph replay per step", "fused": "class-batched step, eager launches",
                                                         "dropin": "drop-in autograd loop"}[args.path]},
-               "loss": loss_value, "roofline": roof}
+               "loss": loss_value, "roofline": roof, "step_work": step_work}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(images_all, indices_class, net, syn, args)
         print(json.dumps(out), flush=True)
