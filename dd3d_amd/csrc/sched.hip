@@ -3,7 +3,7 @@
 // The convolution is output-stationary: a 32-row block skips an offset only when NONE of its rows has that neighbour, and a 128-row
 // tile walks the union of its four blocks' offsets.  In cloud order stroke digits execute 1.37x the algorithmic MFMA work (73 % of the
 // 9 in-plane neighbours present).  Two steps remove most of that:
-//   1. row order: the rows are grouped by their K-bit neighbour pattern -- a counting sort over 4096 hash buckets of the pattern (rows
+//   1. row order: the rows are grouped by their K-bit neighbour pattern -- a counting sort over 4096 buckets of the pattern (rows
 //      with the same pattern share a bucket; which of them comes first inside a bucket is left to the atomics, see below): 1.04x the
 //      algorithmic work at 128-row granularity.  A row's sum does not depend on the rows it shares a block with (the skipped products
 //      are exact zeros), so the convolution's output is bit-identical for ANY order -- the order only decides how fast it runs.
@@ -18,7 +18,7 @@
 
 namespace {
 
-constexpr int NB = 4096;  // hash buckets of the neighbour pattern
+constexpr int NB = 4096;  // buckets of the neighbour pattern
 
 __device__ __forceinline__ unsigned row_pattern(const int* __restrict__ nbr, int64_t ld, int K, int row) {
     int v[27];  // K <= 27: all table reads of the row in flight together
@@ -29,7 +29,17 @@ __device__ __forceinline__ unsigned row_pattern(const int* __restrict__ nbr, int
     for (int k = 0; k < 27; ++k) key |= (unsigned)(k < K && v[k] >= 0) << k;
     return key;
 }
-__device__ __forceinline__ int pattern_bucket(unsigned key) { return (int)((key * 0x9E3779B1u) >> 20); }
+// Bucket of a pattern = 12 of its bits: the 8 non-centre offsets with first spatial coordinate 0 (k = 1 + 3a + 9b; ALL the offsets that
+// planar clouds such as MNIST ever have, so every distinct pattern of theirs gets a bucket of its own) and 4 offsets out of that plane
+// (k = 12, 14: the two face neighbours; k = 3, 23: two edge neighbours).  Rows of volumetric clouds have far more than 4096 distinct
+// patterns; there the rows of a bucket agree on these 12 offsets, and the ~2/3 of them that are absent are skipped by every block of
+// the bucket (a hash of the whole pattern would mix unrelated rows and skip nothing).
+__device__ __forceinline__ int pattern_bucket(unsigned key) {
+    const unsigned plane = ((key >> 1) & 1u) | ((key >> 4) & 1u) << 1 | ((key >> 7) & 1u) << 2 | ((key >> 10) & 1u) << 3 | ((key >> 16) & 1u) << 4 |
+                           ((key >> 19) & 1u) << 5 | ((key >> 22) & 1u) << 6 | ((key >> 25) & 1u) << 7;
+    const unsigned out = ((key >> 12) & 1u) | ((key >> 14) & 1u) << 1 | ((key >> 3) & 1u) << 2 | ((key >> 23) & 1u) << 3;
+    return (int)(out << 8 | plane);
+}
 
 // keys[i] = pattern of row i; hist[b] += rows of bucket b (one LDS histogram per workgroup of 4096 rows, then one global add per bucket it met)
 __global__ __launch_bounds__(1024) void k_row_keys(const int* __restrict__ nbr, int64_t ld, int K, int M_bound, const int* __restrict__ m_dev,
