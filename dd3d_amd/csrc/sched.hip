@@ -127,6 +127,65 @@ __global__ __launch_bounds__(1024) void k_row_scatter(const unsigned* __restrict
     }
 }
 
+// Second level, for launches of 262144 rows and more (volumetric clouds; planar ones have none of these 12 offsets): inside every first-level bucket the rows are ordered by 12
+// further bits of the pattern (the six edge neighbours that touch the plane's axes first, then six corners), so that a 32-row block of
+// an average bucket agrees on ~5 more offsets.  One workgroup per bucket, counting sort in LDS (ends[b] = the bucket's end: the cursors
+// after k_row_scatter); the order among equal keys is again left to the atomics.
+__device__ __forceinline__ int pattern_bucket2(unsigned key) {
+    constexpr int ks[12] = {26, 24, 20, 18, 8, 6, 17, 15, 11, 9, 21, 5};  // least significant first
+    unsigned b = 0;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) b |= ((key >> ks[j]) & 1u) << j;
+    return (int)b;
+}
+__global__ __launch_bounds__(1024) void k_bucket_refine(const int* __restrict__ ends, const int* __restrict__ perm_in, const unsigned* __restrict__ keys_in,
+                                                        int* __restrict__ perm_out, unsigned* __restrict__ keys_out) {
+    __shared__ int s_cnt[NB];
+    __shared__ int s_w[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int start = b ? ends[b - 1] : 0, end = ends[b];
+    if (end - start <= 0) return;
+    if (end - start <= 32) {  // one block whatever the order
+        if (tid < end - start) {
+            perm_out[start + tid] = perm_in[start + tid];
+            keys_out[start + tid] = keys_in[start + tid];
+        }
+        return;
+    }
+    for (int q = tid; q < NB; q += 1024) s_cnt[q] = 0;
+    __syncthreads();
+    for (int i = start + tid; i < end; i += 1024) atomicAdd(&s_cnt[pattern_bucket2(keys_in[i])], 1);
+    __syncthreads();
+    int v[4], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[j] = s_cnt[tid * 4 + j];
+        sum += v[j];
+    }
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_w[w] = incl;
+    __syncthreads();
+    int base = start + incl - sum;
+    for (int q = 0; q < w; ++q) base += s_w[q];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s_cnt[tid * 4 + j] = base;  // the bin's write cursor
+        base += v[j];
+    }
+    __syncthreads();
+    for (int i = start + tid; i < end; i += 1024) {
+        const unsigned key = keys_in[i];
+        const int pos = atomicAdd(&s_cnt[pattern_bucket2(key)], 1);
+        perm_out[pos] = perm_in[i];
+        keys_out[pos] = key;
+    }
+}
+
 // tile_map[b] = tile that workgroup b runs, or -1.  Up to 2048 tiles (every workgroup resident at once, or nearly): a tile's cost is the number of
 // offsets present in it (thread t folds the 128 patterns of tile t); the tiles are ranked by (cost descending, index) and rank i goes to
 // round i / 256, CU position i % 256 forwards in even rounds and backwards in odd ones.  More tiles than that are dispatched as slots
@@ -191,8 +250,9 @@ __global__ __launch_bounds__(1024) void k_tile_schedule(const unsigned* __restri
 
 struct SchedWs {
     unsigned *keys, *sorted_keys;
-    int* hist;
+    int *hist, *perm_tmp;
 };
+constexpr int64_t REFINE_MIN = 1 << 18;  // rows (bound) from which the second sort level runs (below, a bucket holds too few rows to gain)
 
 int64_t carve(int64_t M, void* ws, SchedWs* out) {
     const int64_t n = M > 0 ? M : 1;
@@ -206,6 +266,7 @@ int64_t carve(int64_t M, void* ws, SchedWs* out) {
     w.keys = (unsigned*)take(n * 4);
     w.sorted_keys = (unsigned*)take(n * 4);
     w.hist = (int*)take(NB * 4);
+    w.perm_tmp = M >= REFINE_MIN ? (int*)take(n * 4) : nullptr;
     if (out) *out = w;
     return off;
 }
@@ -236,9 +297,16 @@ DD3D_API int dd3d_conv_schedule(const int32_t* nbr, int64_t ld, int K, int64_t M
     DD3D_HIP(hipMemsetAsync(w.hist, 0, NB * 4, st));
     k_row_keys<<<dim3(nwg), 1024, 0, st>>>(nbr, ld, K, (int)M, m_dev, w.keys, w.hist);
     k_bucket_scan<<<1, 1024, 0, st>>>(w.hist);
-    k_row_scatter<<<dim3(nwg), 1024, 0, st>>>(w.keys, (int)M, m_dev, w.hist, perm, w.sorted_keys);
+    const unsigned* final_keys = w.sorted_keys;
+    if (M >= REFINE_MIN) {
+        k_row_scatter<<<dim3(nwg), 1024, 0, st>>>(w.keys, (int)M, m_dev, w.hist, w.perm_tmp, w.sorted_keys);
+        k_bucket_refine<<<dim3(NB), 1024, 0, st>>>(w.hist, w.perm_tmp, w.sorted_keys, perm, w.keys);  // the row-order keys are done with: reuse
+        final_keys = w.keys;
+    } else {
+        k_row_scatter<<<dim3(nwg), 1024, 0, st>>>(w.keys, (int)M, m_dev, w.hist, perm, w.sorted_keys);
+    }
     if (dd3d_conv_schedule_tile_rows(M) == 128)
-        k_tile_schedule<128><<<1, 1024, 0, st>>>(w.sorted_keys, (int)M, m_dev, (int)dd3d_conv_schedule_blocks(M), tile_map);
+        k_tile_schedule<128><<<1, 1024, 0, st>>>(final_keys, (int)M, m_dev, (int)dd3d_conv_schedule_blocks(M), tile_map);
     else
         k_tile_schedule<32><<<1, 1024, 0, st>>>(w.sorted_keys, (int)M, m_dev, (int)dd3d_conv_schedule_blocks(M), tile_map);
     DD3D_CHECK_LAUNCH();
