@@ -95,9 +95,11 @@ __global__ __launch_bounds__(1024) void k_bucket_scan(int* __restrict__ hist) {
 // ranks its rows inside the run with LDS atomics.  The order inside a bucket therefore depends on the atomics' arrival; the
 // convolution's output does not (see the file comment).
 __global__ __launch_bounds__(1024) void k_row_scatter(const unsigned* __restrict__ keys, int M_bound, const int* __restrict__ m_dev, int* __restrict__ cursor,
-                                                      int* __restrict__ perm, unsigned* __restrict__ sorted_keys) {
+                                                      int* __restrict__ perm, unsigned* __restrict__ sorted_keys, int* __restrict__ perm_refine,
+                                                      int refine_min) {
     __shared__ int s_cnt[NB], s_base[NB];
     const int M = m_dev ? min(*m_dev, M_bound) : M_bound;
+    if (perm_refine && M >= refine_min) perm = perm_refine;  // a second level follows (decided by the TRUE row count)
     const int i0 = blockIdx.x * 4096;
     if (i0 >= M) return;
     for (int b = threadIdx.x; b < NB; b += 1024) s_cnt[b] = 0;
@@ -139,9 +141,11 @@ __device__ __forceinline__ int pattern_bucket2(unsigned key) {
     return (int)b;
 }
 __global__ __launch_bounds__(1024) void k_bucket_refine(const int* __restrict__ ends, const int* __restrict__ perm_in, const unsigned* __restrict__ keys_in,
-                                                        int* __restrict__ perm_out, unsigned* __restrict__ keys_out) {
+                                                        int* __restrict__ perm_out, unsigned* __restrict__ keys_out, int M_bound,
+                                                        const int* __restrict__ m_dev, int refine_min) {
     __shared__ int s_cnt[NB];
     __shared__ int s_w[16];
+    if ((m_dev ? min(*m_dev, M_bound) : M_bound) < refine_min) return;  // the first level wrote perm itself
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int start = b ? ends[b - 1] : 0, end = ends[b];
     if (end - start <= 0) return;
@@ -192,11 +196,13 @@ __global__ __launch_bounds__(1024) void k_bucket_refine(const int* __restrict__ 
 // free up, where plain order is as good as any.
 template <int TR>  // rows per tile: 128 (k_conv128_rows) or 32 (k_conv128<32,1,4>)
 __global__ __launch_bounds__(1024) void k_tile_schedule(const unsigned* __restrict__ sorted_keys, int M_bound, const int* __restrict__ m_dev, int n_blocks,
-                                                        int* __restrict__ tile_map) {
+                                                        int* __restrict__ tile_map, const unsigned* __restrict__ refined_keys = nullptr,
+                                                        int refine_min = 0) {
     constexpr int MAXT = 2048;  // two tiles per thread
     __shared__ __align__(16) int s_cost[MAXT];
     const int tid = threadIdx.x;
     const int M = m_dev ? min(*m_dev, M_bound) : M_bound;
+    if (refined_keys && M >= refine_min) sorted_keys = refined_keys;
     const int ntile = (M + TR - 1) / TR;
     for (int b = tid; b < n_blocks; b += 1024) tile_map[b] = -1;
     __syncthreads();
@@ -297,16 +303,15 @@ DD3D_API int dd3d_conv_schedule(const int32_t* nbr, int64_t ld, int K, int64_t M
     DD3D_HIP(hipMemsetAsync(w.hist, 0, NB * 4, st));
     k_row_keys<<<dim3(nwg), 1024, 0, st>>>(nbr, ld, K, (int)M, m_dev, w.keys, w.hist);
     k_bucket_scan<<<1, 1024, 0, st>>>(w.hist);
-    const unsigned* final_keys = w.sorted_keys;
-    if (M >= REFINE_MIN) {
-        k_row_scatter<<<dim3(nwg), 1024, 0, st>>>(w.keys, (int)M, m_dev, w.hist, w.perm_tmp, w.sorted_keys);
-        k_bucket_refine<<<dim3(NB), 1024, 0, st>>>(w.hist, w.perm_tmp, w.sorted_keys, perm, w.keys);  // the row-order keys are done with: reuse
-        final_keys = w.keys;
+    if (M >= REFINE_MIN) {  // M may be a bound: the kernels take the second level only when the TRUE count reaches REFINE_MIN
+        k_row_scatter<<<dim3(nwg), 1024, 0, st>>>(w.keys, (int)M, m_dev, w.hist, perm, w.sorted_keys, w.perm_tmp, (int)REFINE_MIN);
+        k_bucket_refine<<<dim3(NB), 1024, 0, st>>>(w.hist, w.perm_tmp, w.sorted_keys, perm, w.keys /* done with: reused */, (int)M, m_dev, (int)REFINE_MIN);
     } else {
-        k_row_scatter<<<dim3(nwg), 1024, 0, st>>>(w.keys, (int)M, m_dev, w.hist, perm, w.sorted_keys);
+        k_row_scatter<<<dim3(nwg), 1024, 0, st>>>(w.keys, (int)M, m_dev, w.hist, perm, w.sorted_keys, nullptr, 0);
     }
     if (dd3d_conv_schedule_tile_rows(M) == 128)
-        k_tile_schedule<128><<<1, 1024, 0, st>>>(final_keys, (int)M, m_dev, (int)dd3d_conv_schedule_blocks(M), tile_map);
+        k_tile_schedule<128><<<1, 1024, 0, st>>>(w.sorted_keys, (int)M, m_dev, (int)dd3d_conv_schedule_blocks(M), tile_map, M >= REFINE_MIN ? w.keys : nullptr,
+                                                 (int)REFINE_MIN);
     else
         k_tile_schedule<32><<<1, 1024, 0, st>>>(w.sorted_keys, (int)M, m_dev, (int)dd3d_conv_schedule_blocks(M), tile_map);
     DD3D_CHECK_LAUNCH();
