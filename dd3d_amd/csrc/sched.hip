@@ -41,23 +41,21 @@ __device__ __forceinline__ int pattern_bucket(unsigned key) {
     return (int)(out << 8 | plane);
 }
 
-// keys[i] = pattern of row i; hist[b] += rows of bucket b (one LDS histogram per workgroup of 4096 rows, then one global add per bucket it met)
+// keys[i] = pattern of row i; hist[b] += rows of bucket b (one LDS histogram per workgroup of 1024 rows -- one row per thread, so that a
+// launch of 87 k rows already spreads over 86 CUs -- then one global add per bucket it met)
 __global__ __launch_bounds__(1024) void k_row_keys(const int* __restrict__ nbr, int64_t ld, int K, int M_bound, const int* __restrict__ m_dev,
                                                    unsigned* __restrict__ keys, int* __restrict__ hist) {
     __shared__ int s_h[NB];
     const int M = m_dev ? min(*m_dev, M_bound) : M_bound;
-    const int i0 = blockIdx.x * 4096;
+    const int i0 = blockIdx.x * 1024;
     if (i0 >= M) return;
     for (int b = threadIdx.x; b < NB; b += 1024) s_h[b] = 0;
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int i = i0 + j * 1024 + threadIdx.x;
-        if (i < M) {
-            const unsigned key = row_pattern(nbr, ld, K, i);
-            keys[i] = key;
-            atomicAdd(&s_h[pattern_bucket(key)], 1);
-        }
+    const int i = i0 + threadIdx.x;
+    if (i < M) {
+        const unsigned key = row_pattern(nbr, ld, K, i);
+        keys[i] = key;
+        atomicAdd(&s_h[pattern_bucket(key)], 1);
     }
     __syncthreads();
     for (int b = threadIdx.x; b < NB; b += 1024)
@@ -146,47 +144,50 @@ __global__ __launch_bounds__(1024) void k_bucket_refine(const int* __restrict__ 
     __shared__ int s_cnt[NB];
     __shared__ int s_w[16];
     if ((m_dev ? min(*m_dev, M_bound) : M_bound) < refine_min) return;  // the first level wrote perm itself
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int start = b ? ends[b - 1] : 0, end = ends[b];
-    if (end - start <= 0) return;
-    if (end - start <= 32) {  // one block whatever the order
-        if (tid < end - start) {
-            perm_out[start + tid] = perm_in[start + tid];
-            keys_out[start + tid] = keys_in[start + tid];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int b = blockIdx.x; b < NB; b += gridDim.x) {  // 512 workgroups, eight buckets each
+        const int start = b ? ends[b - 1] : 0, end = ends[b];
+        if (end - start <= 0) continue;
+        if (end - start <= 32) {  // one block whatever the order
+            if (tid < end - start) {
+                perm_out[start + tid] = perm_in[start + tid];
+                keys_out[start + tid] = keys_in[start + tid];
+            }
+            continue;
         }
-        return;
-    }
-    for (int q = tid; q < NB; q += 1024) s_cnt[q] = 0;
-    __syncthreads();
-    for (int i = start + tid; i < end; i += 1024) atomicAdd(&s_cnt[pattern_bucket2(keys_in[i])], 1);
-    __syncthreads();
-    int v[4], sum = 0;
+        for (int q = tid; q < NB; q += 1024) s_cnt[q] = 0;
+        __syncthreads();
+        for (int i = start + tid; i < end; i += 1024) atomicAdd(&s_cnt[pattern_bucket2(keys_in[i])], 1);
+        __syncthreads();
+        int v[4], sum = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        v[j] = s_cnt[tid * 4 + j];
-        sum += v[j];
-    }
-    int incl = sum;
+        for (int j = 0; j < 4; ++j) {
+            v[j] = s_cnt[tid * 4 + j];
+            sum += v[j];
+        }
+        int incl = sum;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
-    }
-    if (lane == 63) s_w[w] = incl;
-    __syncthreads();
-    int base = start + incl - sum;
-    for (int q = 0; q < w; ++q) base += s_w[q];
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) s_w[w] = incl;
+        __syncthreads();
+        int base = start + incl - sum;
+        for (int q = 0; q < w; ++q) base += s_w[q];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        s_cnt[tid * 4 + j] = base;  // the bin's write cursor
-        base += v[j];
-    }
-    __syncthreads();
-    for (int i = start + tid; i < end; i += 1024) {
-        const unsigned key = keys_in[i];
-        const int pos = atomicAdd(&s_cnt[pattern_bucket2(key)], 1);
-        perm_out[pos] = perm_in[i];
-        keys_out[pos] = key;
+        for (int j = 0; j < 4; ++j) {
+            s_cnt[tid * 4 + j] = base;  // the bin's write cursor
+            base += v[j];
+        }
+        __syncthreads();
+        for (int i = start + tid; i < end; i += 1024) {
+            const unsigned key = keys_in[i];
+            const int pos = atomicAdd(&s_cnt[pattern_bucket2(key)], 1);
+            perm_out[pos] = perm_in[i];
+            keys_out[pos] = key;
+        }
+        __syncthreads();  // s_cnt / s_w are reused by the next bucket
     }
 }
 
@@ -301,11 +302,11 @@ DD3D_API int dd3d_conv_schedule(const int32_t* nbr, int64_t ld, int K, int64_t M
     hipStream_t st = (hipStream_t)stream;
     const unsigned nwg = (unsigned)ceil_div64(M, 4096);
     DD3D_HIP(hipMemsetAsync(w.hist, 0, NB * 4, st));
-    k_row_keys<<<dim3(nwg), 1024, 0, st>>>(nbr, ld, K, (int)M, m_dev, w.keys, w.hist);
+    k_row_keys<<<dim3((unsigned)ceil_div64(M, 1024)), 1024, 0, st>>>(nbr, ld, K, (int)M, m_dev, w.keys, w.hist);
     k_bucket_scan<<<1, 1024, 0, st>>>(w.hist);
     if (M >= REFINE_MIN) {  // M may be a bound: the kernels take the second level only when the TRUE count reaches REFINE_MIN
         k_row_scatter<<<dim3(nwg), 1024, 0, st>>>(w.keys, (int)M, m_dev, w.hist, perm, w.sorted_keys, w.perm_tmp, (int)REFINE_MIN);
-        k_bucket_refine<<<dim3(NB), 1024, 0, st>>>(w.hist, w.perm_tmp, w.sorted_keys, perm, w.keys /* done with: reused */, (int)M, m_dev, (int)REFINE_MIN);
+        k_bucket_refine<<<dim3(512), 1024, 0, st>>>(w.hist, w.perm_tmp, w.sorted_keys, perm, w.keys /* done with: reused */, (int)M, m_dev, (int)REFINE_MIN);
     } else {
         k_row_scatter<<<dim3(nwg), 1024, 0, st>>>(w.keys, (int)M, m_dev, w.hist, perm, w.sorted_keys, nullptr, 0);
     }
