@@ -72,6 +72,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    local %= max(torch.cuda.device_count(), 1)   # a launcher that shows every rank only its own GPU numbers it 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1 or os.environ.get("DD3D_FORCE_DIST"):   # DD3D_FORCE_DIST: rehearse the RCCL path with a single rank
