@@ -226,7 +226,8 @@ __device__ CloudCounts build_cloud(CloudSmem<NMAX>& S, const float4* __restrict_
 template <int NMAX>
 __global__ __launch_bounds__(CT) void k_cloud_count(const float4* __restrict__ coords, const int* __restrict__ pt_off, int B,
                                                     const int* __restrict__ cloud_group, int* __restrict__ cnt /*[3][B]*/, int* gmin /*[G][3]*/,
-                                                    int* err) {
+                                                    int* err, int* __restrict__ cmin /*[3][B] or null*/, int* __restrict__ vox_at /*[S][B] or null*/,
+                                                    int S_sites) {
     constexpr int HC = CloudSmem<NMAX>::HC;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     CloudSmem<NMAX>& S = *reinterpret_cast<CloudSmem<NMAX>*>(smem_raw);
@@ -239,6 +240,8 @@ __global__ __launch_bounds__(CT) void k_cloud_count(const float4* __restrict__ c
     }
     for (int i = tid; i < HC; i += CT) S.tab1[i] = S.tab2[i] = S.tab4[i] = -1;
     if (tid < 6) S.s_w[tid] = tid < 3 ? 0 : 0x7F7F7F7F;
+    if (vox_at)  // this cloud's column of the dense table starts empty (k_cloud_emit fills it in): no memset node
+        for (int s = tid; s < S_sites; s += CT) vox_at[(int64_t)s * B + b] = -1;
     bool bad = false;
     for (int i = tid; i < n; i += CT) {
         const float4 c = coords[p0 + i];
@@ -297,7 +300,8 @@ __global__ __launch_bounds__(CT) void k_cloud_count(const float4* __restrict__ c
         // one global atomic per cloud and axis, and only when it can lower the group's corner (most clouds share it): the values only
         // decrease, so a stale read costs an unnecessary atomic at worst
         const int m = S.s_w[3 + tid];
-        if (gmin && m != big) {
+        if (cmin) cmin[tid * B + b] = m;  // folded per group by k_cloud_scan
+        else if (gmin && m != big) {
             int* dst = &gmin[(cloud_group ? cloud_group[b] : 0) * 3 + tid];
             if (m < __atomic_load_n(dst, __ATOMIC_RELAXED)) atomicMin(dst, m);
         }
@@ -305,11 +309,24 @@ __global__ __launch_bounds__(CT) void k_cloud_count(const float4* __restrict__ c
 }
 
 // ---- scan: seg[l][0..B] = exclusive prefix of cnt[l][0..B), counts[l] = total, for the three levels (one block) ----
+constexpr int GMIN_LDS_GROUPS = 1024;  // groups whose minimum corners k_cloud_scan folds in LDS (more: global atomics after a memset)
 __global__ void k_cloud_scan(const int* __restrict__ cnt, int B, int* __restrict__ seg /*[3][B+1]*/, int* __restrict__ counts /*[3]*/,
-                             const int* __restrict__ group_cloud_off, int G, int* __restrict__ gro /*[3][G+1] or null*/) {
+                             const int* __restrict__ group_cloud_off, int G, int* __restrict__ gro /*[3][G+1] or null*/,
+                             const int* __restrict__ cmin /*[3][B] or null*/, const int* __restrict__ cloud_group, int* __restrict__ gmin /*[G][3]*/) {
     __shared__ int s_w[16];
     __shared__ int s_carry;
+    __shared__ int s_gmin[GMIN_LDS_GROUPS * 3];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (cmin) {  // gmin[g][a] = min over the clouds of group g (G <= GMIN_LDS_GROUPS, checked by the host)
+        for (int i = threadIdx.x; i < G * 3; i += 1024) s_gmin[i] = 0x7F7F7F7F;
+        __syncthreads();
+        for (int i = threadIdx.x; i < 3 * B; i += 1024) {
+            const int a = i / B, b = i - a * B;
+            atomicMin(&s_gmin[(cloud_group ? cloud_group[b] : 0) * 3 + a], cmin[i]);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < G * 3; i += 1024) gmin[i] = s_gmin[i];
+    }
     for (int l = 0; l < 3; ++l) {
         if (threadIdx.x == 0) s_carry = 0;
         __syncthreads();
@@ -494,13 +511,14 @@ __global__ __launch_bounds__(CT) void k_cloud_emit(const float4* __restrict__ co
 template <int NMAX>
 int launch_cloud_maps(const float4* coords, const int* pt_off, int B, const int* cloud_group, int* cnt, int* seg, int* counts, const CloudOut& o,
                       int* gmin, int* err, const int* group_cloud_off, int G, int* gro, hipStream_t st) {
+    int* cmin = (gmin && G <= GMIN_LDS_GROUPS) ? cnt + 3 * (int64_t)B : nullptr;
     const size_t smem = sizeof(CloudSmem<NMAX>);
     if (smem > 64 * 1024) {
         DD3D_HIP(hipFuncSetAttribute((const void*)k_cloud_count<NMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         DD3D_HIP(hipFuncSetAttribute((const void*)k_cloud_emit<NMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     }
-    k_cloud_count<NMAX><<<dim3(B), CT, smem, st>>>(coords, pt_off, B, cloud_group, cnt, gmin, err);
-    k_cloud_scan<<<1, 1024, 0, st>>>(cnt, B, seg, counts, group_cloud_off, G, gro);
+    k_cloud_count<NMAX><<<dim3(B), CT, smem, st>>>(coords, pt_off, B, cloud_group, cnt, gmin, err, cmin, o.vox_at, o.E0 * o.E1 * o.E2);
+    k_cloud_scan<<<1, 1024, 0, st>>>(cnt, B, seg, counts, group_cloud_off, G, gro, cmin, cloud_group, gmin);
     k_cloud_emit<NMAX><<<dim3(B), CT, smem, st>>>(coords, pt_off, B, cloud_group, seg, o, err);
     DD3D_CHECK_LAUNCH();
     return 0;
@@ -510,7 +528,7 @@ int launch_cloud_maps(const float4* coords, const int* pt_off, int B, const int*
 
 DD3D_API int dd3d_cloud_maps_max_points(void) { return 1024; }
 
-DD3D_API int64_t dd3d_cloud_maps_ws_bytes(int B) { return align_up64((int64_t)(B > 0 ? B : 1) * 3 * 4, 256); }
+DD3D_API int64_t dd3d_cloud_maps_ws_bytes(int B) { return align_up64((int64_t)(B > 0 ? B : 1) * 6 * 4, 256); }  // counts and minimum corners, [3][B] each
 
 // See include/dd3d.h.  All outputs are sized by `bound` (>= number of points); rows beyond the counts are not written.
 DD3D_API int dd3d_cloud_maps(const float* coords, const int32_t* pt_off, int B, int max_points, int64_t bound, const int32_t* cloud_group, int G,
@@ -528,10 +546,9 @@ DD3D_API int dd3d_cloud_maps(const float* coords, const int32_t* pt_off, int B, 
     if (vox_at && !dense) return DD3D_EARG;
     if (group_row_off && !group_cloud_off) return DD3D_EARG;
     hipStream_t st = (hipStream_t)stream;
-    if (dense) {
-        DD3D_HIP(hipMemsetAsync(gmin, 0x7F, (size_t)G * 3 * 4, st));
-        if (vox_at && B > 0) DD3D_HIP(hipMemsetAsync(vox_at, 0xFF, (size_t)B * E0 * E1 * E2 * 4, st));
-    }
+    // the dense table is cleared per cloud by k_cloud_count and the group corners are folded by k_cloud_scan: no memset nodes in a
+    // captured step (only more groups than the scan holds in LDS, or no clouds at all, take the memset)
+    if (dense && (G > GMIN_LDS_GROUPS || B == 0)) DD3D_HIP(hipMemsetAsync(gmin, 0x7F, (size_t)G * 3 * 4, st));
     if (B == 0) {
         DD3D_HIP(hipMemsetAsync(counts, 0, 12, st));
         DD3D_HIP(hipMemsetAsync(seg, 0, 12, st));
