@@ -62,15 +62,38 @@ __global__ __launch_bounds__(1024) void k_row_keys(const int* __restrict__ nbr, 
         if (s_h[b]) atomicAdd(&hist[b], s_h[b]);
 }
 
-// hist -> exclusive prefix, in place (it then serves as the buckets' write cursors)
-__global__ __launch_bounds__(1024) void k_bucket_scan(int* __restrict__ hist) {
+// perm / sorted_keys: every workgroup scans the bucket counts itself (4096 ints from L2: cheaper than a scan kernel of its own in the
+// dependent chain), reserves, per bucket it holds, a run behind the bucket's fill counter (one global atomic) and ranks its rows inside
+// the run with LDS atomics.  The order inside a bucket therefore depends on the atomics' arrival; the convolution's output does not
+// (see the file comment).  Workgroup 0 also writes ends[b] = end of bucket b (what the second level walks).
+__global__ __launch_bounds__(1024) void k_row_scatter(const unsigned* __restrict__ keys, int M_bound, const int* __restrict__ m_dev,
+                                                      const int* __restrict__ hist, int* __restrict__ fill, int* __restrict__ ends,
+                                                      int* __restrict__ perm, unsigned* __restrict__ sorted_keys, int* __restrict__ perm_refine,
+                                                      int refine_min) {
+    __shared__ int s_cnt[NB], s_base[NB];
     __shared__ int s_w[16];
+    const int M = m_dev ? min(*m_dev, M_bound) : M_bound;
+    if (perm_refine && M >= refine_min) perm = perm_refine;  // a second level follows (decided by the TRUE row count)
+    const int i0 = blockIdx.x * 4096;
+    if (i0 >= M) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     int v[4], sum = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         v[j] = hist[tid * 4 + j];
         sum += v[j];
+    }
+    for (int b = tid; b < NB; b += 1024) s_cnt[b] = 0;
+    unsigned key[4];
+    int bucket[4], rank[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = i0 + j * 1024 + tid;
+        bucket[j] = -1;
+        if (i < M) {
+            key[j] = keys[i];
+            bucket[j] = pattern_bucket(key[j]);
+        }
     }
     int incl = sum;
 #pragma unroll
@@ -84,51 +107,28 @@ __global__ __launch_bounds__(1024) void k_bucket_scan(int* __restrict__ hist) {
     for (int q = 0; q < w; ++q) base += s_w[q];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        hist[tid * 4 + j] = base;
+        s_base[tid * 4 + j] = base;  // first position of bucket tid*4+j
         base += v[j];
+        if (blockIdx.x == 0) ends[tid * 4 + j] = base;
     }
-}
-
-// perm / sorted_keys: every workgroup reserves, per bucket, a run behind the bucket's cursor (one global atomic per bucket it holds) and
-// ranks its rows inside the run with LDS atomics.  The order inside a bucket therefore depends on the atomics' arrival; the
-// convolution's output does not (see the file comment).
-__global__ __launch_bounds__(1024) void k_row_scatter(const unsigned* __restrict__ keys, int M_bound, const int* __restrict__ m_dev, int* __restrict__ cursor,
-                                                      int* __restrict__ perm, unsigned* __restrict__ sorted_keys, int* __restrict__ perm_refine,
-                                                      int refine_min) {
-    __shared__ int s_cnt[NB], s_base[NB];
-    const int M = m_dev ? min(*m_dev, M_bound) : M_bound;
-    if (perm_refine && M >= refine_min) perm = perm_refine;  // a second level follows (decided by the TRUE row count)
-    const int i0 = blockIdx.x * 4096;
-    if (i0 >= M) return;
-    for (int b = threadIdx.x; b < NB; b += 1024) s_cnt[b] = 0;
-    __syncthreads();
-    unsigned key[4];
-    int bucket[4], rank[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int i = i0 + j * 1024 + threadIdx.x;
-        bucket[j] = -1;
-        if (i < M) {
-            key[j] = keys[i];
-            bucket[j] = pattern_bucket(key[j]);
-            rank[j] = atomicAdd(&s_cnt[bucket[j]], 1);
-        }
-    }
+    for (int j = 0; j < 4; ++j)
+        if (bucket[j] >= 0) rank[j] = atomicAdd(&s_cnt[bucket[j]], 1);
     __syncthreads();
-    for (int b = threadIdx.x; b < NB; b += 1024)
-        if (s_cnt[b]) s_base[b] = atomicAdd(&cursor[b], s_cnt[b]);
+    for (int b = tid; b < NB; b += 1024)
+        if (s_cnt[b]) s_base[b] += atomicAdd(&fill[b], s_cnt[b]);
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if (bucket[j] < 0) continue;
         const int pos = s_base[bucket[j]] + rank[j];
-        perm[pos] = i0 + j * 1024 + threadIdx.x;
+        perm[pos] = i0 + j * 1024 + tid;
         sorted_keys[pos] = key[j];
     }
 }
 
-// Second level, for launches of 262144 rows and more (volumetric clouds; planar ones have none of these 12 offsets): inside every first-level bucket the rows are ordered by 12
-// further bits of the pattern (the six edge neighbours that touch the plane's axes first, then six corners), so that a 32-row block of
+// Second level, for launches of at least 262144 rows under a bound of 2^20 or more (volumetric clouds; planar ones have none of these 12
+// offsets): inside every first-level bucket the rows are ordered by 12 further bits of the pattern (the six edge neighbours that touch the plane's axes first, then six corners), so that a 32-row block of
 // an average bucket agrees on ~5 more offsets.  One workgroup per bucket, counting sort in LDS (ends[b] = the bucket's end: the cursors
 // after k_row_scatter); the order among equal keys is again left to the atomics.
 __device__ __forceinline__ int pattern_bucket2(unsigned key) {
@@ -257,9 +257,10 @@ __global__ __launch_bounds__(1024) void k_tile_schedule(const unsigned* __restri
 
 struct SchedWs {
     unsigned *keys, *sorted_keys;
-    int *hist, *perm_tmp;
+    int *hist, *fill, *ends, *perm_tmp;  // hist and fill are adjacent: one memset
 };
-constexpr int64_t REFINE_MIN = 1 << 18;  // rows (bound) from which the second sort level runs (below, a bucket holds too few rows to gain)
+constexpr int64_t REFINE_MIN = 1 << 18;         // true rows from which the second sort level runs (below, a bucket holds too few rows to gain)
+constexpr int64_t REFINE_LAUNCH_MIN = 1 << 20;  // row bound from which its kernel is launched at all (an idle node still costs the chain ~15 us)
 
 int64_t carve(int64_t M, void* ws, SchedWs* out) {
     const int64_t n = M > 0 ? M : 1;
@@ -272,8 +273,10 @@ int64_t carve(int64_t M, void* ws, SchedWs* out) {
     SchedWs w;
     w.keys = (unsigned*)take(n * 4);
     w.sorted_keys = (unsigned*)take(n * 4);
-    w.hist = (int*)take(NB * 4);
-    w.perm_tmp = M >= REFINE_MIN ? (int*)take(n * 4) : nullptr;
+    w.hist = (int*)take(2 * NB * 4);
+    w.fill = w.hist ? w.hist + NB : nullptr;
+    w.ends = (int*)take(NB * 4);
+    w.perm_tmp = M >= REFINE_LAUNCH_MIN ? (int*)take(n * 4) : nullptr;
     if (out) *out = w;
     return off;
 }
@@ -301,17 +304,15 @@ DD3D_API int dd3d_conv_schedule(const int32_t* nbr, int64_t ld, int K, int64_t M
     carve(M, ws, &w);
     hipStream_t st = (hipStream_t)stream;
     const unsigned nwg = (unsigned)ceil_div64(M, 4096);
-    DD3D_HIP(hipMemsetAsync(w.hist, 0, NB * 4, st));
+    DD3D_HIP(hipMemsetAsync(w.hist, 0, 2 * NB * 4, st));
     k_row_keys<<<dim3((unsigned)ceil_div64(M, 1024)), 1024, 0, st>>>(nbr, ld, K, (int)M, m_dev, w.keys, w.hist);
-    k_bucket_scan<<<1, 1024, 0, st>>>(w.hist);
-    if (M >= REFINE_MIN) {  // M may be a bound: the kernels take the second level only when the TRUE count reaches REFINE_MIN
-        k_row_scatter<<<dim3(nwg), 1024, 0, st>>>(w.keys, (int)M, m_dev, w.hist, perm, w.sorted_keys, w.perm_tmp, (int)REFINE_MIN);
-        k_bucket_refine<<<dim3(512), 1024, 0, st>>>(w.hist, w.perm_tmp, w.sorted_keys, perm, w.keys /* done with: reused */, (int)M, m_dev, (int)REFINE_MIN);
-    } else {
-        k_row_scatter<<<dim3(nwg), 1024, 0, st>>>(w.keys, (int)M, m_dev, w.hist, perm, w.sorted_keys, nullptr, 0);
-    }
+    const bool refine = M >= REFINE_LAUNCH_MIN;  // M may be a bound: the kernels take the second level only when the TRUE count reaches REFINE_MIN
+    k_row_scatter<<<dim3(nwg), 1024, 0, st>>>(w.keys, (int)M, m_dev, w.hist, w.fill, w.ends, perm, w.sorted_keys, refine ? w.perm_tmp : nullptr,
+                                              (int)REFINE_MIN);
+    if (refine)
+        k_bucket_refine<<<dim3(512), 1024, 0, st>>>(w.ends, w.perm_tmp, w.sorted_keys, perm, w.keys /* done with: reused */, (int)M, m_dev, (int)REFINE_MIN);
     if (dd3d_conv_schedule_tile_rows(M) == 128)
-        k_tile_schedule<128><<<1, 1024, 0, st>>>(w.sorted_keys, (int)M, m_dev, (int)dd3d_conv_schedule_blocks(M), tile_map, M >= REFINE_MIN ? w.keys : nullptr,
+        k_tile_schedule<128><<<1, 1024, 0, st>>>(w.sorted_keys, (int)M, m_dev, (int)dd3d_conv_schedule_blocks(M), tile_map, refine ? w.keys : nullptr,
                                                  (int)REFINE_MIN);
     else
         k_tile_schedule<32><<<1, 1024, 0, st>>>(w.sorted_keys, (int)M, m_dev, (int)dd3d_conv_schedule_blocks(M), tile_map);

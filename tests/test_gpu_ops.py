@@ -422,11 +422,11 @@ def _random_table(M, K, p, seed):
 
 
 @pytest.mark.parametrize("M,bound", [(70001, 70001), (66000, 80000), (3000, 3000), (150000, 150000), (300000, 300000), (20000, 30000), (40000, 40000), (1, 5),
-                                     (1100000, 1100000), (1050000, 1200000), (66000, 300000)])
+                                     (1100000, 1100000), (1050000, 1200000), (66000, 300000), (66000, 1100000)])
 def test_scheduled_conv128_is_bit_identical(M, bound):
     """dd3d_conv_schedule + dd3d_conv128_ordered against dd3d_conv_fwd (itself checked against the oracle above): same bits for the
     forward and the mirrored launch, with an exact count and with a bound + device-side count; the schedule is a permutation of the rows
-    and covers every tile once.  Sizes on both sides of the 2048-tile limit of the placement and of the 262144 rows from which the
+    and covers every tile once.  Sizes on both sides of the 2048-tile limit of the placement and of the row counts from which the
     second sort level runs."""
     from dd3d_amd import _lib as L
     d = dev()
