@@ -195,15 +195,37 @@ __global__ __launch_bounds__(1024) void k_bucket_refine(const int* __restrict__ 
 // offsets present in it (thread t folds the 128 patterns of tile t); the tiles are ranked by (cost descending, index) and rank i goes to
 // round i / 256, CU position i % 256 forwards in even rounds and backwards in odd ones.  More tiles than that are dispatched as slots
 // free up, where plain order is as good as any.
+// cost[t] = offsets present in tile t (thread t folds the tile's patterns: 64 cache lines per load instruction, which one CU alone takes
+// 40 us to get through -- hence a kernel of its own, 64 tiles per workgroup)
 template <int TR>  // rows per tile: 128 (k_conv128_rows) or 32 (k_conv128<32,1,4>)
-__global__ __launch_bounds__(1024) void k_tile_schedule(const unsigned* __restrict__ sorted_keys, int M_bound, const int* __restrict__ m_dev, int n_blocks,
-                                                        int* __restrict__ tile_map, const unsigned* __restrict__ refined_keys = nullptr,
-                                                        int refine_min = 0) {
+__global__ __launch_bounds__(64) void k_tile_cost(const unsigned* __restrict__ sorted_keys, int M_bound, const int* __restrict__ m_dev,
+                                                  const unsigned* __restrict__ refined_keys, int refine_min, int* __restrict__ cost) {
+    const int M = m_dev ? min(*m_dev, M_bound) : M_bound;
+    if (refined_keys && M >= refine_min) sorted_keys = refined_keys;
+    const int ntile = (M + TR - 1) / TR, t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= ntile || t >= 2048) return;
+    unsigned u = 0;
+    const uint4* k4 = (const uint4*)(sorted_keys + (int64_t)t * TR);   // TR * 4 B aligned: the workspace carve is 256-B aligned
+    const int n = min(TR, M - t * TR);
+    if (n == TR) {  // TR / 4 independent 16-B loads
+        uint4 q[TR / 4];
+#pragma unroll
+        for (int i = 0; i < TR / 4; ++i) q[i] = k4[i];
+#pragma unroll
+        for (int i = 0; i < TR / 4; ++i) u |= q[i].x | q[i].y | q[i].z | q[i].w;
+    } else {
+        for (int i = 0; i < n; ++i) u |= sorted_keys[(int64_t)t * TR + i];
+    }
+    cost[t] = __popc(u);
+}
+
+template <int TR>
+__global__ __launch_bounds__(1024) void k_tile_schedule(const int* __restrict__ g_cost, int M_bound, const int* __restrict__ m_dev, int n_blocks,
+                                                        int* __restrict__ tile_map) {
     constexpr int MAXT = 2048;  // two tiles per thread
     __shared__ __align__(16) int s_cost[MAXT];
     const int tid = threadIdx.x;
     const int M = m_dev ? min(*m_dev, M_bound) : M_bound;
-    if (refined_keys && M >= refine_min) sorted_keys = refined_keys;
     const int ntile = (M + TR - 1) / TR;
     for (int b = tid; b < n_blocks; b += 1024) tile_map[b] = -1;
     __syncthreads();
@@ -215,22 +237,7 @@ __global__ __launch_bounds__(1024) void k_tile_schedule(const unsigned* __restri
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int t = tid + j * 1024;
-        int c = -1;
-        if (t < ntile) {
-            unsigned u = 0;
-            const uint4* k4 = (const uint4*)(sorted_keys + (int64_t)t * TR);   // TR * 4 B aligned: the workspace carve is 256-B aligned
-            const int n = min(TR, M - t * TR);
-            if (n == TR) {  // TR / 4 independent 16-B loads
-                uint4 q[TR / 4];
-#pragma unroll
-                for (int i = 0; i < TR / 4; ++i) q[i] = k4[i];
-#pragma unroll
-                for (int i = 0; i < TR / 4; ++i) u |= q[i].x | q[i].y | q[i].z | q[i].w;
-            } else {
-                for (int i = 0; i < n; ++i) u |= sorted_keys[(int64_t)t * TR + i];
-            }
-            c = __popc(u);
-        }
+        const int c = t < ntile ? g_cost[t] : -1;
         cost[j] = c;
         s_cost[t] = c;
     }
@@ -257,7 +264,7 @@ __global__ __launch_bounds__(1024) void k_tile_schedule(const unsigned* __restri
 
 struct SchedWs {
     unsigned *keys, *sorted_keys;
-    int *hist, *fill, *ends, *perm_tmp;  // hist and fill are adjacent: one memset
+    int *hist, *fill, *ends, *cost, *perm_tmp;  // hist and fill are adjacent: one memset
 };
 constexpr int64_t REFINE_MIN = 1 << 18;         // true rows from which the second sort level runs (below, a bucket holds too few rows to gain)
 constexpr int64_t REFINE_LAUNCH_MIN = 1 << 20;  // row bound from which its kernel is launched at all (an idle node still costs the chain ~15 us)
@@ -276,6 +283,7 @@ int64_t carve(int64_t M, void* ws, SchedWs* out) {
     w.hist = (int*)take(2 * NB * 4);
     w.fill = w.hist ? w.hist + NB : nullptr;
     w.ends = (int*)take(NB * 4);
+    w.cost = (int*)take(2048 * 4);
     w.perm_tmp = M >= REFINE_LAUNCH_MIN ? (int*)take(n * 4) : nullptr;
     if (out) *out = w;
     return off;
@@ -311,11 +319,16 @@ DD3D_API int dd3d_conv_schedule(const int32_t* nbr, int64_t ld, int K, int64_t M
                                               (int)REFINE_MIN);
     if (refine)
         k_bucket_refine<<<dim3(512), 1024, 0, st>>>(w.ends, w.perm_tmp, w.sorted_keys, perm, w.keys /* done with: reused */, (int)M, m_dev, (int)REFINE_MIN);
-    if (dd3d_conv_schedule_tile_rows(M) == 128)
-        k_tile_schedule<128><<<1, 1024, 0, st>>>(w.sorted_keys, (int)M, m_dev, (int)dd3d_conv_schedule_blocks(M), tile_map, refine ? w.keys : nullptr,
-                                                 (int)REFINE_MIN);
-    else
-        k_tile_schedule<32><<<1, 1024, 0, st>>>(w.sorted_keys, (int)M, m_dev, (int)dd3d_conv_schedule_blocks(M), tile_map);
+    // the placement uses the costs of up to 2048 tiles (of the TRUE row count: M may be a bound)
+    const int nb = (int)dd3d_conv_schedule_blocks(M);
+    const int64_t tr = dd3d_conv_schedule_tile_rows(M), nt = ceil_div64(M, tr) < 2048 ? ceil_div64(M, tr) : 2048;
+    if (tr == 128) {
+        k_tile_cost<128><<<dim3((unsigned)ceil_div64(nt, 64)), 64, 0, st>>>(w.sorted_keys, (int)M, m_dev, refine ? w.keys : nullptr, (int)REFINE_MIN, w.cost);
+        k_tile_schedule<128><<<1, 1024, 0, st>>>(w.cost, (int)M, m_dev, nb, tile_map);
+    } else {
+        k_tile_cost<32><<<dim3((unsigned)ceil_div64(nt, 64)), 64, 0, st>>>(w.sorted_keys, (int)M, m_dev, nullptr, 0, w.cost);
+        k_tile_schedule<32><<<1, 1024, 0, st>>>(w.cost, (int)M, m_dev, nb, tile_map);
+    }
     DD3D_CHECK_LAUNCH();
     return 0;
 }
