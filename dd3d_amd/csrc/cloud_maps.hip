@@ -322,7 +322,9 @@ __global__ void k_cloud_scan(const int* __restrict__ cnt, int B, int* __restrict
         __syncthreads();
         for (int i = threadIdx.x; i < 3 * B; i += 1024) {
             const int a = i / B, b = i - a * B;
-            atomicMin(&s_gmin[(cloud_group ? cloud_group[b] : 0) * 3 + a], cmin[i]);
+            int* dst = &s_gmin[(cloud_group ? cloud_group[b] : 0) * 3 + a];
+            const int v = cmin[i];
+            if (v < *(volatile int*)dst) atomicMin(dst, v);  // values only decrease: a stale read costs a needless atomic at worst
         }
         __syncthreads();
         for (int i = threadIdx.x; i < G * 3; i += 1024) gmin[i] = s_gmin[i];
