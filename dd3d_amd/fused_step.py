@@ -30,8 +30,9 @@ from .ops import DensePlacement, _site_strides, site_major, sl_bwd_x_call, sl_fw
 from .sparse import CloudCoordinateManager, CoordinateManager
 from .utils.Mnist2D import batch_from_images
 
-# row bound up to which the second-order 128-channel convolution (synthetic rows only) runs offsets-split (dd3d_conv128_split)
-SPLIT_MAX_ROWS = int(os.environ.get("DD3D_CONV_SPLIT_MAX", "65536"))
+# row bound (= synthetic points) up to which the second-order 128-channel convolution runs offsets-split (dd3d_conv128_split); beyond 512
+# tiles the split count is 1 anyway and the plain launch saves the idle summing node
+SPLIT_MAX_ROWS = int(os.environ.get("DD3D_CONV_SPLIT_MAX", "16384"))
 
 _F32, _I32 = torch.float32, torch.int32
 
