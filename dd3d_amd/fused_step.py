@@ -302,24 +302,24 @@ def compact_site_major(cls_w: torch.Tensor, C: int, full, compact) -> torch.Tens
 
 class _GradList(list):
     """Per-parameter gradient list [G, *shape] whose classifier-weight entry is held over the reachable sites only; indexing it
-    returns the parameter-shaped tensor (zeros elsewhere), expanded on first use.  The step itself never expands it."""
+    returns the parameter-shaped tensor (zeros elsewhere), expanded on every access: in graph mode the list wraps fixed buffers that
+    the next replay overwrites, so nothing derived from them may be cached.  The step itself never expands it."""
 
     def __init__(self, tensors, full, compact, C=128):
         super().__init__(tensors)
-        self._full, self._compact, self._C, self._done = tuple(full), tuple(compact), C, tuple(full) == tuple(compact)
+        self._full, self._compact, self._C, self._same = tuple(full), tuple(compact), C, tuple(full) == tuple(compact)
 
     def compact(self, i):
         return list.__getitem__(self, i)
 
     def __getitem__(self, i):
-        if i in (6, -2) and not self._done:
+        if i in (6, -2) and not self._same:
             t = list.__getitem__(self, 6)
             G, J = t.shape[0], t.shape[1]
             S = self._full[0] * self._full[1] * self._full[2]
             out = torch.zeros((G, J, self._C, S), dtype=t.dtype, device=t.device)
             out[..., reachable_sites(self._full, self._compact).to(t.device)] = t.reshape(G, J, self._C, -1)
-            list.__setitem__(self, 6, out.reshape(G, J, self._C * S))
-            self._done = True
+            return out.reshape(G, J, self._C * S)
         return list.__getitem__(self, i)
 
     def __iter__(self):

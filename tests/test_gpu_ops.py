@@ -498,3 +498,85 @@ def test_offsets_split_conv128_matches_plain_and_oracle(M, bound, mirror):
             ref[has] += Xd[idx[has]] @ Wd[k]
         assert rel_err(outs[0][:M], ref) < 2e-5
     assert L.lib.dd3d_conv128_split(L.ptr(X_d), M, L.ptr(W_d), L.ptr(nbr_d), bound, 27, bound, None, 0, L.ptr(outs[0]), L.ptr(ws), 16, st) == -3
+
+
+def _fp64_conv(X, W, nbr, M, mirror):
+    """Y[o] = sum_k X[nbr[k'][o]] . W[k], k' = 26 - k for the mirrored launch -- per-offset fp64 matmuls on the CPU."""
+    ref = torch.zeros(M, 128, dtype=torch.float64)
+    Xd, Wd = X.double(), W.double()
+    for k in range(27):
+        idx = nbr[26 - k if mirror else k, :M].long()
+        has = idx >= 0
+        ref[has] += Xd[idx[has]] @ Wd[k]
+    return ref
+
+
+@pytest.mark.parametrize("M,bound", [(70001, 70001), (90000, 131072)])
+@pytest.mark.parametrize("mirror", [0, 1])
+def test_large_conv128_rows_kernel_vs_fp64_oracle(M, bound, mirror):
+    """The launches the bench runs: from 65536 rows on dd3d_conv_fwd and dd3d_conv128_ordered select k_conv128_rows<4> (128-row tiles,
+    row-private waves).  Both, forward and mirrored (the backward-data launch), against per-offset fp64 matmuls; rel 2e-5 of the
+    tensor's max magnitude, with an exact count and with a bound + device-side count."""
+    from dd3d_amd import _lib as L
+    d = dev()
+    assert int(L.lib.dd3d_conv_schedule_tile_rows(bound)) == 128
+    nbr = _random_table(bound, 27, 0.4, M + mirror)
+    nbr[nbr >= M] = -1
+    g = torch.Generator().manual_seed(M)
+    X = torch.randn(bound, 128, generator=g)
+    W = torch.randn(27, 128, 128, generator=g) * 0.05
+    ref = _fp64_conv(X, W, nbr, M, mirror)
+    nbr_d, X_d, W_d = nbr.to(d), X.to(d), W.to(d)
+    m_dev = torch.tensor([M], dtype=torch.int32, device=d) if bound != M else None
+    Y = torch.full((bound, 128), 7.0, device=d)
+    L.call("dd3d_conv_fwd", L.ptr(X_d), bound, 128, L.ptr(W_d), 128, L.ptr(nbr_d), bound, 27, bound, L.ptr(m_dev), mirror, L.ptr(Y), L.stream())
+    e1 = rel_err(Y[:M], ref)
+    perm = torch.empty((bound,), dtype=torch.int32, device=d)
+    tmap = torch.empty((int(L.lib.dd3d_conv_schedule_blocks(bound)),), dtype=torch.int32, device=d)
+    ws = torch.empty(int(L.lib.dd3d_conv_schedule_ws_bytes(bound)), dtype=torch.uint8, device=d)
+    L.call("dd3d_conv_schedule", L.ptr(nbr_d), bound, 27, bound, L.ptr(m_dev), L.ptr(perm), L.ptr(tmap), L.ptr(ws), ws.numel(), L.stream())
+    Y2 = torch.full((bound, 128), 7.0, device=d)
+    L.call("dd3d_conv128_ordered", L.ptr(X_d), bound, L.ptr(W_d), L.ptr(nbr_d), bound, 27, bound, L.ptr(m_dev), mirror, L.ptr(perm), L.ptr(tmap),
+           L.ptr(Y2), L.stream())
+    e2 = rel_err(Y2[:M], ref)
+    print(f"conv128_rows M={M} mirror={mirror}: plain {e1:.2e} ordered {e2:.2e}")
+    assert e1 < 2e-5 and e2 < 2e-5
+    assert bool((Y[M:] == 7.0).all()) and bool((Y2[M:] == 7.0).all())
+
+
+@pytest.mark.parametrize("M,bound", [(70001, 70001), (90000, 131072)])
+def test_large_conv128_bwd_weight_vs_fp64_oracle(M, bound):
+    """dd3d_conv_bwd_weight, Cin = 128, at the row counts of the bench (>= 65536 rows: 512-row chunks), two groups of rows, against fp64
+    X[nbr]^T dY per offset and group; bitwise reproducible; a bound-sized launch gives the bits of the exact one."""
+    from dd3d_amd import _lib as L
+    d = dev()
+    nbr = _random_table(bound, 27, 0.4, M + 5)
+    nbr[nbr >= M] = -1
+    g = torch.Generator().manual_seed(M + 1)
+    X = torch.randn(bound, 128, generator=g)
+    dY = torch.randn(bound, 128, generator=g)
+    cut = M // 3
+    gro = torch.tensor([0, cut, M], dtype=torch.int32, device=d)
+    nbr_d, X_d, dY_d = nbr.to(d), X.to(d), dY.to(d)
+
+    def run(bnd):
+        dW = torch.full((2, 27, 128, 128), 7.0, device=d)
+        ws = torch.empty(int(L.lib.dd3d_conv_bwd_weight_ws_bytes(bnd, 2, 27, 128, 128)), dtype=torch.uint8, device=d)
+        ws.fill_(0xFF)
+        L.call("dd3d_conv_bwd_weight", L.ptr(X_d), 128, L.ptr(dY_d), 128, L.ptr(nbr_d), bound, 27, bnd, L.ptr(gro), 2, L.ptr(dW), L.ptr(ws), ws.numel(),
+               L.stream())
+        return dW
+    dW = run(bound)
+    assert torch.equal(dW, run(bound))
+    if bound != M:
+        assert torch.equal(dW, run(M))
+    Xd, Dd = X.double(), dY.double()
+    for gi, (a, b) in enumerate(((0, cut), (cut, M))):
+        ref = torch.zeros(27, 128, 128, dtype=torch.float64)
+        for k in range(27):
+            o = torch.nonzero(nbr[k, a:b] >= 0).reshape(-1) + a
+            if o.numel():
+                ref[k] = Xd[nbr[k][o].long()].t() @ Dd[o]
+        e = rel_err(dW[gi], ref)
+        print(f"conv128 bwd-weight M={M} group {gi}: {e:.2e}")
+        assert e < 2e-5

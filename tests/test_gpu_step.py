@@ -119,8 +119,10 @@ def test_mepytorch_step_vs_reference_golden(metric):
         loss = d.outer_step(real_batches=batches, apply_update=False)
     finally:
         settings.Pyt = False
-    assert loss.item() == pytest.approx(float(g[metric + ".loss"]), rel=2e-4)
-    assert rel_err(d.last["grad"], g[metric + ".grad"]) < 2e-4
+    e_loss = abs(loss.item() - float(g[metric + ".loss"])) / abs(float(g[metric + ".loss"]))
+    e_grad = rel_err(d.last["grad"], g[metric + ".grad"])
+    print(f"MEPytorch {metric}: loss rel {e_loss:.2e}, xyz-grad rel {e_grad:.2e}")
+    assert e_loss < 1e-4 and e_grad < 1e-4   # north_star tolerance
     for c in range(2):
         assert rel_err(d.last["logits"][c][0], g[metric + ".logits_real"][c]) < 1e-4
 
