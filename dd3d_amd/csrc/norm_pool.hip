@@ -644,3 +644,36 @@ DD3D_API int dd3d_arp_inorm_bwd(const float* g_pool, const int32_t* arg, const i
     DD3D_CHECK_LAUNCH();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// dd3d_arp_inorm_bwd for callers that cannot allocate (code under HIP-graph capture with a frozen memory pool, tight serving loops,
+// harnesses that forbid hipMalloc): the per-cloud partial sums part[B][2][32] float4 live in a file-scope device array instead of a
+// caller workspace.  The array's NAME is a host-side stand-in, not a device address: its address on each device is taken once with
+// hipGetSymbolAddress (with that device current) and kept per device; host code only ever uses that pointer.
+// ---------------------------------------------------------------------------------------------
+#define DD3D_ARP_STATIC_MAX_CLOUDS 8192
+static __device__ __align__(256) float scratch[(size_t)DD3D_ARP_STATIC_MAX_CLOUDS * 2 * 128];  // 8 MiB per GPU, held until the process ends
+
+#define DD3D_MAX_DEVICES 64
+static void* g_scratch_ptr[DD3D_MAX_DEVICES];  // device address of `scratch` on every GPU this process has called from (0 = not taken yet)
+
+DD3D_API int dd3d_arp_inorm_bwd_static_max_clouds(void) { return DD3D_ARP_STATIC_MAX_CLOUDS; }
+
+DD3D_API int dd3d_arp_inorm_bwd_static(const float* g_pool, const int32_t* arg, const int32_t* parent, const float* xhat, const float* inv_std,
+                                       const float* w, const float* b, int C, const int32_t* seg_off, int B, const int32_t* cloud_group,
+                                       const int32_t* group_cloud_off, int G, float* dY, float* ga_out, int ga_clouds, const float* ga_prev,
+                                       const float* gw_extra, float* gw_w, float* gw_b, void* stream) {
+    if (B > DD3D_ARP_STATIC_MAX_CLOUDS) return DD3D_ESIZE;  // more clouds than the static scratch holds: use dd3d_arp_inorm_bwd with a workspace
+    int dev = -1;
+    DD3D_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= DD3D_MAX_DEVICES) return DD3D_ESIZE;
+    void* p = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+    if (!p) {  // first call on this device (it is the current one): no allocation, the array is part of the loaded code object
+        DD3D_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return (int)hipErrorInvalidSymbol;
+        __atomic_store_n(&g_scratch_ptr[dev], p, __ATOMIC_RELEASE);  // racing first calls store the same address
+    }
+    // every slot part[b], b < B, is written by the kernel before k_cloud_group_sum reads it (empty clouds write zeros): nothing to clear
+    return dd3d_arp_inorm_bwd(g_pool, arg, parent, xhat, inv_std, w, b, C, seg_off, B, cloud_group, group_cloud_off, G, dY, ga_out, ga_clouds, ga_prev,
+                              gw_extra, gw_w, gw_b, p, (int64_t)sizeof(float) * DD3D_ARP_STATIC_MAX_CLOUDS * 2 * 128, stream);
+}

@@ -201,6 +201,18 @@ int dd3d_arp_inorm_bwd(const float* g_pool, const int32_t* arg, const int32_t* p
                        const float* b, int C, const int32_t* seg_off, int B, const int32_t* cloud_group, const int32_t* group_cloud_off, int G,
                        float* dY, float* ga_out, int ga_clouds /* ga_out is written for clouds < ga_clouds only; <= 0: all */, const float* ga_prev, const float* gw_extra, float* gw_w, float* gw_b, void* ws, int64_t ws_bytes,
                        void* stream);
+/* dd3d_arp_inorm_bwd without a workspace argument and without any allocation.  NO COUNTERPART IN THE REFERENCE: it exists for
+ * callers that cannot allocate -- code under HIP-graph capture, tight serving loops, harnesses that forbid hipMalloc.  The per-cloud
+ * partial sums (2 x 128 floats per cloud) live in a file-scope device array of the library, 8 MiB per GPU, held until the process
+ * ends; its device address is taken once per device with hipGetSymbolAddress.  B > dd3d_arp_inorm_bwd_static_max_clouds() (8192)
+ * returns -2 (use dd3d_arp_inorm_bwd with a caller workspace there).  Same kernels, same outputs bit for bit.  All calls on one GPU
+ * share that GPU's array: calls that overlap on one GPU (two streams, two threads) race -- serialise them.  Nothing needs clearing
+ * between calls: every slot a call reads, it has written. */
+int dd3d_arp_inorm_bwd_static_max_clouds(void);
+int dd3d_arp_inorm_bwd_static(const float* g_pool, const int32_t* arg, const int32_t* parent, const float* xhat, const float* inv_std,
+                              const float* w, const float* b, int C, const int32_t* seg_off, int B, const int32_t* cloud_group,
+                              const int32_t* group_cloud_off, int G, float* dY, float* ga_out, int ga_clouds, const float* ga_prev,
+                              const float* gw_extra, float* gw_w, float* gw_b, void* stream);
 int dd3d_scale_rows_by_group(const float* ga, const float* gw, const int32_t* group_row_off, int G, int64_t M, int C, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------------
