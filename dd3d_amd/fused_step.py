@@ -51,7 +51,7 @@ class _Pass:
     pass is the same kernels called on the first ``B_syn`` clouds with the prefix's row counts (``seg_off[B_syn]``, on the device)."""
 
     def __init__(self, net, coords, B, G, cloud_group, group_cloud_off, B_syn, N_syn, side, n_dev=None, static=False, pt_off=None, max_points=0,
-                 extent=None):
+                 extent=None, side2=None):
         """Phase 1 (no host sync): every coordinate map, enqueued on the current stream.
         ``static``: never read a size back -- every launch covers its bound and takes the true row count from the device
         (``n_dev`` = number of valid rows of ``coords``), so the pass can be captured into a HIP graph."""
@@ -59,7 +59,7 @@ class _Pass:
         self.dev, self.B, self.G, self.net = dev, B, G, net
         self.B_syn, self.N_syn, self.Gs = B_syn, N_syn, G // 2
         self.cloud_group, self.gco = cloud_group, group_cloud_off
-        self.static, self.side = static, side
+        self.static, self.side, self.side2 = static, side, side2 if side2 is not None else side
         # dense() placement over `extent` sites per axis: the network's dense extent, or the (smaller) box the voxels can actually reach
         self.extent = extent = tuple(net.dense_extent) if extent is None else tuple(extent)
         if pt_off is not None and 0 < max_points <= int(L.lib.dd3d_cloud_maps_max_points()):
@@ -166,26 +166,43 @@ class _Pass:
             pst = (ctypes.c_int64 * 4)(J * 128 * S, 128 * S, S, 1)
             L.call("dd3d_sparse_linear_bwd_w", L.ptr(dl), L.ptr(P1), L.ptr(dp.vox_at), S, B, L.ptr(group_cloud_off), G, 128, J, L.ptr(g_cw), pst,
                    g_cw.numel(), L.stream())
+            self.ev_cls = torch.cuda.Event()
+            self.ev_cls.record(side)
         gP1 = _empty((M2, 128), dev)
         sl_bwd_x_call(dl, dp, None, Wsm, sst, J, 0, gP1)
         # the ReLU-masked pooled gradients (ga) are kept for the synthetic clouds only: the second-order pass needs nothing else
         Ns = max(self.N_syn, 1)
         self.ga1, self.ga0 = _empty((Ns, 128), dev), _empty((Ns, 128), dev)
         gY1, g_w5, g_b5 = self._arp_inorm_bwd(gP1, arg1, cm.parent(4), xh1, is1, w5, b5, seg2, M1, B, G, self.ga1, self.B_syn, True)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            g_W1 = self._bww(P0, 128, gY1, k1, ld1, M1, gro2)
+        # Two launches want the matrix cores here: the input gradient of the 128-channel convolution (main stream, everything else waits
+        # for it) and its kernel gradient (side stream, only the loss value waits for it).  Side by side they share the pipe and BOTH take
+        # ~400 us; with the kernel gradient held back until the input gradient is done (DD3D_BWW_AFTER, default) the main stream gets the
+        # pipe for ~200 us and the kernel gradient then overlaps the bandwidth-bound norm / pool backward and the second-order pass.
+        after = os.environ.get("DD3D_BWW_AFTER", "1") != "0"
+        if not after:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                g_W1 = self._bww(P0, 128, gY1, k1, ld1, M1, gro2)
         gP0 = _empty((M1, 128), dev)
         if self.sched is not None:
             L.call("dd3d_conv128_ordered", L.ptr(gY1), M1, L.ptr(W1t), L.ptr(k1), ld1, 27, M1, c1, 1, L.ptr(self.sched[0]), L.ptr(self.sched[1]),
                    L.ptr(gP0), st)
         else:
             L.call("dd3d_conv_bwd_data", L.ptr(gY1), M1, c1, 128, L.ptr(W1t), 128, L.ptr(k1), ld1, 27, L.ptr(gP0), st)
+        if after:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                g_W1 = self._bww(P0, 128, gY1, k1, ld1, M1, gro2)
         gY0, g_w1, g_b1 = self._arp_inorm_bwd(gP0, arg0, cm.parent(2), xh0, is0, w1, b1, seg1, M0, B, G, self.ga0, self.B_syn, True)
-        g_W0 = self._bww(F0, 3, gY0, k0, ld0, M0, gro1)
-        main.wait_stream(side)
+        # The first layer's kernel gradient feeds nothing but the loss VALUE either: it runs on a stream of its own next to the 128-channel
+        # one (bandwidth-bound next to matrix-bound), and the main stream goes on to the matching loss of the differentiable entries and
+        # the second-order pass (the caller joins the streams: FusedDistiller._compute)
+        side2 = self.side2
+        side2.wait_stream(main)
+        with torch.cuda.stream(side2):
+            g_W0 = self._bww(F0, 3, gY0, k0, ld0, M0, gro1)
         if not self.static:
-            for t in (g_cb, g_cw, g_W1):   # allocated on the side stream, consumed on the main one
+            for t in (g_cb, g_cw, g_W1, g_W0):   # allocated on the side stream, consumed on the main one
                 t.record_stream(main)
         # order of network.parameters()
         self.gw = [g_W0, g_w1, g_b1, g_W1, g_w5, g_b5, g_cw, g_cb]
@@ -250,7 +267,8 @@ class _Pass:
 
 
 def grouped_match_loss(gw_syn: List[torch.Tensor], gw_real: List[torch.Tensor], dis_metric: str, G: int, need_grad, pyt: bool = False):
-    """distillation_loss.match_loss for G classes at once: tensors are [G, *param_shape]; returns (loss[G], grads list)."""
+    """distillation_loss.match_loss for G classes at once: tensors are [G, *param_shape]; returns (loss[G], grads list).  With no gradient
+    requested only the forward launches run."""
     if dis_metric not in _METRICS:
         exit("unknown distance function: %s" % dis_metric)
     metric = _METRICS[dis_metric]
@@ -269,7 +287,8 @@ def grouped_match_loss(gw_syn: List[torch.Tensor], gw_real: List[torch.Tensor], 
     loss = _empty((G,), dev)
     ws = L.workspace(int(L.lib.dd3d_match_loss_ws_bytes(segs, n, G)), dev)
     L.call("dd3d_match_loss_fwd", segs, n, G, metric, L.ptr(loss), L.ptr(stats), L.ptr(ws), ws.numel(), L.stream())
-    L.call("dd3d_match_loss_bwd", segs, n, G, metric, L.ptr(stats), None, L.ptr(ws), ws.numel(), L.stream())
+    if any(need_grad):
+        L.call("dd3d_match_loss_bwd", segs, n, G, metric, L.ptr(stats), None, L.ptr(ws), ws.numel(), L.stream())
     return loss, dsyn
 
 
@@ -376,6 +395,7 @@ class FusedDistiller:
         self.syn_batch_col = torch.arange(G * ipc, device=dev, dtype=_F32).repeat_interleave(num_points)[:, None]
         self.last = {}
         self.stream_side = torch.cuda.Stream(dev)   # parameter-gradient kernels that only the loss consumes
+        self.stream_side2 = torch.cuda.Stream(dev)  # the first layer's kernel gradient, next to the 128-channel one
         # eager mode: next step's real batch is sampled on its own stream while this step's kernels run
         self.stream_data, self._prefetched = torch.cuda.Stream(dev), None
         self.use_graph = bool(graph) and G > 0
@@ -556,13 +576,33 @@ class FusedDistiller:
         compact_site_major(net.classifier.weight, 128, net.dense_extent, extent)
         transposed_kernel(net.features[4].kernel)
         p = _Pass(net, mb["coordinates"], int(mb["num_clouds"]), 2 * G, mb["cloud_group"], mb["group_cloud_off"], G * ipc, G * ipc * npts,
-                  self.stream_side, mb.get("n_dev"), static, mb.get("pt_off"), npts, extent)
+                  self.stream_side, mb.get("n_dev"), static, mb.get("pt_off"), npts, extent, self.stream_side2)
         p.run(mb["features"], mb["labels"])
         gw_syn, gw_real = [t[:G] for t in p.gw], [t[G:] for t in p.gw]
-        # only these entries of gw_syn depend on the synthetic points: IN weights, classifier weight and bias
-        need = [False, True, False, False, True, False, True, True]
-        loss_g, d = grouped_match_loss(gw_syn, gw_real, self.dist_opt, G, need)
-        dfeats = p.backward_to_points(d[1], d[4], d[6], d[7], ipc)
+        # Only these entries of gw_syn depend on the synthetic points: IN weights, classifier weight and bias.  For the
+        # layer-additive metrics the loss is split accordingly: the part over these four entries (with its gradient) runs on the main stream
+        # as soon as they exist, and the second-order pass follows at once; the VALUE of the other four (both kernel gradients, both IN
+        # biases) is added from the side stream, where the kernel gradients are still being computed.  'cos' normalises over all
+        # layers together and keeps the joint launch.
+        main, side = torch.cuda.current_stream(dev), self.stream_side
+        diff, const = [1, 4, 6, 7], [0, 2, 3, 5]
+        if self.dist_opt in ("ours", "modmse", "mse") and os.environ.get("DD3D_LOSS_SPLIT", "1") != "0":
+            main.wait_event(p.ev_cls)
+            loss_a, d4 = grouped_match_loss([gw_syn[i] for i in diff], [gw_real[i] for i in diff], self.dist_opt, G, [True] * 4)
+            side.wait_stream(p.side2)
+            with torch.cuda.stream(side):
+                loss_b, _ = grouped_match_loss([gw_syn[i] for i in const], [gw_real[i] for i in const], self.dist_opt, G, [False] * 4)
+            dfeats = p.backward_to_points(d4[0], d4[1], d4[2], d4[3], ipc)
+            main.wait_stream(side)
+            if not static:
+                loss_b.record_stream(main)
+            loss_g = loss_a + loss_b
+        else:
+            main.wait_stream(side)
+            main.wait_stream(p.side2)
+            need = [i in diff for i in range(8)]
+            loss_g, d = grouped_match_loss(gw_syn, gw_real, self.dist_opt, G, need)
+            dfeats = p.backward_to_points(d[1], d[4], d[6], d[7], ipc)
         grad = torch.empty_like(self.image_syn)
         fused_tail = self._apply_update and self.image_syn.shape[1] == npts
         if not fused_tail:
