@@ -69,6 +69,8 @@ class _Pass:
             cm = CoordinateManager(coords, B, n_dev=n_dev)
         self.cm = cm
         self.N = cm.N
+        # every cloud has at most max_points voxel rows at any stride: small enough for the cloud-window kernel gradient?
+        self.small_clouds = pt_off is not None and 0 < max_points <= int(L.lib.dd3d_conv128_bwd_weight_clouds_max_rows())
         k0, p0 = cm.kernel_map(1, 1, 3), cm.kernel_map(1, 2, 2)
         k1, p1 = cm.kernel_map(2, 2, 3), cm.kernel_map(2, 4, 2)
         seg1, seg2 = cm.seg_off(1), cm.seg_off(2)
@@ -182,7 +184,7 @@ class _Pass:
         if not after:
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                g_W1 = self._bww(P0, 128, gY1, k1, ld1, M1, gro2)
+                g_W1 = self._bww(P0, 128, gY1, k1, ld1, M1, gro2, seg2)
         gP0 = _empty((M1, 128), dev)
         if self.sched is not None:
             L.call("dd3d_conv128_ordered", L.ptr(gY1), M1, L.ptr(W1t), L.ptr(k1), ld1, 27, M1, c1, 1, L.ptr(self.sched[0]), L.ptr(self.sched[1]),
@@ -192,7 +194,7 @@ class _Pass:
         if after:
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                g_W1 = self._bww(P0, 128, gY1, k1, ld1, M1, gro2)
+                g_W1 = self._bww(P0, 128, gY1, k1, ld1, M1, gro2, seg2)
         gY0, g_w1, g_b1 = self._arp_inorm_bwd(gP0, arg0, cm.parent(2), xh0, is0, w1, b1, seg1, M0, B, G, self.ga0, self.B_syn, True)
         # The first layer's kernel gradient feeds nothing but the loss VALUE either: it runs on a stream of its own next to the 128-channel
         # one (bandwidth-bound next to matrix-bound), and the main stream goes on to the matching loss of the differentiable entries and
@@ -221,9 +223,17 @@ class _Pass:
                L.ptr(gw_b), L.ptr(ws), ws.numel(), L.stream())
         return dY, gw_w, gw_b
 
-    def _bww(self, X, Cin, dY, nbr, ld, M, gro):
+    def _bww(self, X, Cin, dY, nbr, ld, M, gro, seg=None):
         G = self.G
         dW = _empty((G, 27, Cin, 128), self.dev)
+        if Cin == 128 and seg is not None and self.small_clouds and os.environ.get("DD3D_BWW_CLOUDS", "0") != "0":
+            # small clouds: whole-cloud windows of both operands in LDS (conv_bww.hip).  Off by default: alone it takes what the row-chunk kernel
+            # and its slab sum take (243 + 10 us against 223 + 30 us at cfg2, with a quarter of the memory traffic), but its workgroups fill a
+            # CU's registers, so next to the main stream's kernels it starves them (measured: step 1.497 against 1.455 ms)
+            ws = L.workspace(int(L.lib.dd3d_conv128_bwd_weight_clouds_ws_bytes(M, G)), self.dev)
+            L.call("dd3d_conv128_bwd_weight_clouds", L.ptr(X), L.ptr(dY), L.ptr(nbr), ld, 27, M, L.ptr(seg), self.B, L.ptr(gro), G, L.ptr(dW),
+                   L.ptr(self.cm.err), L.ptr(ws), ws.numel(), L.stream())
+            return dW
         ws = L.workspace(int(L.lib.dd3d_conv_bwd_weight_ws_bytes(M, G, 27, Cin, 128)), self.dev)
         L.call("dd3d_conv_bwd_weight", L.ptr(X), Cin, L.ptr(dY), 128, L.ptr(nbr), ld, 27, M, L.ptr(gro), G, L.ptr(dW), L.ptr(ws), ws.numel(),
                L.stream())

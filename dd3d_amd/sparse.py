@@ -110,6 +110,8 @@ class CoordinateManager:
             raise RuntimeError("coordinates are not grouped by ascending batch index (or a batch index is out of range)")
         if err & 2:
             raise IndexError("dense(): a voxel falls outside the requested dense shape")
+        if err & 16:
+            raise RuntimeError("a cloud has more voxel rows than the cloud-window kernel gradient holds")
 
     def _rows_bound(self, lv: _Level) -> int:
         return lv.M if lv.M is not None else lv.bound

@@ -157,6 +157,21 @@ int64_t dd3d_conv_bwd_weight_ws_bytes(int64_t M_out, int G, int K, int Cin, int 
 int dd3d_conv_bwd_weight(const float* X, int Cin, const float* dY, int Cout, const int32_t* nbr, int64_t ld, int K, int64_t M_out,
                          const int32_t* group_row_off, int G, float* dW, void* ws, int64_t ws_bytes, void* stream);
 
+/* dd3d_conv_bwd_weight for Cin = Cout = 128, K = 27 over a batch of SMALL clouds (every cloud at most
+ * dd3d_conv128_bwd_weight_clouds_max_rows() = 256 rows), the cloud-window form: seg_off[B+1] = first row of every cloud (rows grouped by
+ * cloud, clouds grouped by group, as dd3d_cloud_maps / dd3d_segment_offsets deliver them); a neighbour never leaves its cloud, so a
+ * workgroup keeps a window of whole clouds of X and dY in LDS and every product reads its operands from there: each operand row comes
+ * from HBM/L2 once per quarter-workgroup instead of once per offset, and the partial sums stay in registers over ~M/64 rows.  Same
+ * result as dd3d_conv_bwd_weight to fp32 rounding (another, equally fixed, summation order); bitwise reproducible; M_out may be a bound
+ * (the chunking follows group_row_off[G], read on the device).  *err_dev |= 16 if a cloud has more rows than the window holds (its
+ * pairs are then missing from dW: route such batches to dd3d_conv_bwd_weight), |= 1 if a neighbour lies outside its row's cloud.
+ * replaces: ConvolutionBackwardGPU (kernel gradient) reached by torch.autograd.grad, mnist_distill.py:349,359 via models/MEConv.py:224 */
+int dd3d_conv128_bwd_weight_clouds_max_rows(void);
+int64_t dd3d_conv128_bwd_weight_clouds_ws_bytes(int64_t M_out, int G);
+int dd3d_conv128_bwd_weight_clouds(const float* X, const float* dY, const int32_t* nbr, int64_t ld, int K, int64_t M_out, const int32_t* seg_off,
+                                   int B, const int32_t* group_row_off, int G, float* dW, int32_t* err_dev, void* ws, int64_t ws_bytes,
+                                   void* stream);
+
 /* Wt[k][co][ci] = W[k][ci][co] */
 int dd3d_transpose_kernel(const float* W, int K, int Cin, int Cout, float* Wt, void* stream);
 

@@ -580,3 +580,76 @@ def test_large_conv128_bwd_weight_vs_fp64_oracle(M, bound):
         e = rel_err(dW[gi], ref)
         print(f"conv128 bwd-weight M={M} group {gi}: {e:.2e}")
         assert e < 2e-5
+
+
+def _cloud_batch_maps(B, pts, seed, groups):
+    """Stride-2 kernel map of a batch of flat clouds + per-cloud / per-group row ranges (what the fused step hands the kernel gradient)."""
+    coords = make_coords(B=B, pts=pts, extent=28, seed=seed)
+    cm = manager(coords, B)
+    nbr, ld = cm.kernel_map(2, 2, 3)
+    seg = cm.seg_off(2)
+    M = cm.num_rows(2)
+    gco = torch.tensor(groups, device=dev())
+    return cm, nbr, ld, seg, M, seg[gco.long()].contiguous().to(torch.int32)
+
+
+@pytest.mark.parametrize("B,pts,groups", [(40, 300, [0, 7, 7, 25, 40]), (700, 250, [0, 100, 350, 700]), (3, 40, [0, 3]), (2600, 120, [0, 100, 200, 1400, 2600])])
+def test_cloud_window_bwd_weight_vs_fp64_and_row_chunk_kernel(B, pts, groups):
+    """dd3d_conv128_bwd_weight_clouds (LDS windows of whole clouds) against fp64 X[nbr]^T dY per offset and group and against the row-chunk
+    kernel dd3d_conv_bwd_weight; bitwise reproducible; a bound-sized launch (rows beyond the count garbage) gives the same bits."""
+    from dd3d_amd import _lib as L
+    from dd3d_amd.ops import conv_bwd_weight
+    d = dev()
+    cm, nbr, ld, seg, M, gro = _cloud_batch_maps(B, pts, 31 + B, groups)
+    G = len(groups) - 1
+    g = torch.Generator().manual_seed(B)
+    X = torch.randn(M, 128, generator=g)
+    dY = torch.randn(M, 128, generator=g)
+    err = torch.zeros(1, dtype=torch.int32, device=d)
+
+    def run(bound, Xd, Dd):
+        dW = torch.full((G, 27, 128, 128), 7.0, device=d)
+        ws = torch.empty(int(L.lib.dd3d_conv128_bwd_weight_clouds_ws_bytes(bound, G)), dtype=torch.uint8, device=d)
+        ws.fill_(0xFF)
+        L.call("dd3d_conv128_bwd_weight_clouds", L.ptr(Xd), L.ptr(Dd), L.ptr(nbr), ld, 27, bound, L.ptr(seg), B, L.ptr(gro), G, L.ptr(dW), L.ptr(err),
+               L.ptr(ws), ws.numel(), L.stream())
+        return dW
+    Xd, Dd = X.to(d), dY.to(d)
+    dW = run(M, Xd, Dd)
+    assert int(err.item()) == 0
+    assert torch.equal(dW, run(M, Xd, Dd))
+    pad = lambda t: torch.cat([t, torch.full((ld - M, 128), float("nan"), device=d)]) if ld > M else t
+    assert torch.equal(dW, run(ld, pad(Xd), pad(Dd)))
+    old = conv_bwd_weight(Xd, Dd, nbr, ld, M, gro, G)
+    ref_nbr = nbr[:, :M].cpu().long()
+    rows = gro.cpu().tolist()
+    X64, D64 = X.double(), dY.double()
+    for gi in range(G):
+        a, b = rows[gi], rows[gi + 1]
+        ref = torch.zeros(27, 128, 128, dtype=torch.float64)
+        for k in range(27):
+            o = torch.nonzero(ref_nbr[k, a:b] >= 0).reshape(-1) + a
+            if o.numel():
+                ref[k] = X64[ref_nbr[k][o]].t() @ D64[o]
+        if a == b:
+            assert float(dW[gi].abs().max()) == 0.0
+        else:
+            assert rel_err(dW[gi], ref) < 2e-5 and rel_err(dW[gi], old[gi]) < 2e-5
+
+
+def test_cloud_window_bwd_weight_flags_a_cloud_larger_than_the_window():
+    from dd3d_amd import _lib as L
+    d = dev()
+    cm, nbr, ld, seg, M, gro = _cloud_batch_maps(2, 2500, 5, [0, 2])   # ~190 stride-2 voxels per cloud of a 28 x 28 grid at most: force one cloud
+    one = torch.tensor([0, M, M], dtype=torch.int32, device=d)         # pretend all rows are ONE cloud: more than 256 rows
+    if M <= int(L.lib.dd3d_conv128_bwd_weight_clouds_max_rows()):
+        pytest.skip("batch too small to overflow the window")
+    err = torch.zeros(1, dtype=torch.int32, device=d)
+    X = torch.randn(M, 128, device=d)
+    dW = torch.empty((1, 27, 128, 128), device=d)
+    ws = torch.empty(int(L.lib.dd3d_conv128_bwd_weight_clouds_ws_bytes(M, 1)), dtype=torch.uint8, device=d)
+    L.call("dd3d_conv128_bwd_weight_clouds", L.ptr(X), L.ptr(X), L.ptr(nbr), ld, 27, M, L.ptr(one), 2, L.ptr(gro), 1, L.ptr(dW), L.ptr(err), L.ptr(ws),
+           ws.numel(), L.stream())
+    assert int(err.item()) & 16
+    assert L.lib.dd3d_conv128_bwd_weight_clouds(L.ptr(X), L.ptr(X), L.ptr(nbr), ld, 27, M, L.ptr(one), 2, L.ptr(gro), 1, L.ptr(dW), L.ptr(err), L.ptr(ws), 16,
+                                                L.stream()) == -3

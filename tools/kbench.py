@@ -59,6 +59,7 @@ K = {
  "arp_inorm_bwd L1": (lambda: L.call("dd3d_arp_inorm_bwd", L.ptr(gP0), L.ptr(arg0), L.ptr(cm.parent(2)), L.ptr(xh0), L.ptr(is0), L.ptr(w), L.ptr(bb), 128, L.ptr(seg1), B,
                                      L.ptr(cg), L.ptr(gco), G, L.ptr(gY0), None, 0, None, None, L.ptr(gw_w), L.ptr(gw_b), L.ptr(ws), ws.numel(), st), 1024 * M0 + 1024 * M1),
  "conv128_bww": (lambda: L.call("dd3d_conv_bwd_weight", L.ptr(P0), 128, L.ptr(gY1), 128, L.ptr(k1), ld1, 27, M1, L.ptr(gro2), G, L.ptr(dW1), L.ptr(ws), ws.numel(), st), 0),
+ "conv128_bww_clouds": (lambda: L.call("dd3d_conv128_bwd_weight_clouds", L.ptr(P0), L.ptr(gY1), L.ptr(k1), ld1, 27, M1, L.ptr(seg2), B, L.ptr(gro2), G, L.ptr(dW1), L.ptr(cm.err), L.ptr(ws), ws.numel(), st), 0),
  "conv3_bww": (lambda: L.call("dd3d_conv_bwd_weight", L.ptr(F0), 3, L.ptr(gY0), 128, L.ptr(k0), ld0, 27, M0, L.ptr(gro1), G, L.ptr(dW0), L.ptr(ws), ws.numel(), st), 512 * M0 + 120 * M0),
 }
 from dd3d_amd.sparse import CloudCoordinateManager
