@@ -383,27 +383,18 @@ __global__ __launch_bounds__(256) void k_arp_reduce(const f32x4* __restrict__ pa
 // write.  Per-cloud partial sums of ga*xhat / ga go to part[b][2][32]; k_cloud_group_sum folds them per group in cloud order.
 // grid (cloud, 32 / CL): a workgroup takes CL float4 channel-lanes (CL * 16 B of every row), so several workgroups per CU overlap
 // their gather latencies (CL = 8: 128-B pieces of a row, one cache line)
-template <int RL, int CACHE, int CL>
-__global__ __launch_bounds__(RL * CL) void k_arp_inorm_bwd(const f32x4* __restrict__ g_pool, const int4* __restrict__ arg, const int* __restrict__ parent,
-                                                           const f32x4* __restrict__ xhat, const f32x4* __restrict__ inv_std,
-                                                           const f32x4* __restrict__ w, const f32x4* __restrict__ bias,
-                                                           const int* __restrict__ seg_off, const int* __restrict__ cloud_group,
-                                                           f32x4* __restrict__ dY, f32x4* __restrict__ ga_out_all, int ga_clouds,
-                                                           const f32x4* __restrict__ ga_prev, const f32x4* __restrict__ gw_extra,
-                                                           f32x4* __restrict__ part /*[B][2][32] or null*/) {
-    __shared__ f32x4 s_red[4 * (RL * CL / 64) * CL];
-    const int b = blockIdx.x, c4 = blockIdx.y * CL + threadIdx.x % CL, rl = threadIdx.x / CL;
-    const int r0 = seg_off[b], r1 = seg_off[b + 1];
+// One cloud x one channel slice.  WAVE = false: the slice belongs to a workgroup of RL row-lanes x CL float4 channel-lanes (column sums through
+// LDS, two barriers).  WAVE = true: the slice belongs to ONE wave of 8 row-lanes x 8 channel-lanes (column sums by three shuffle steps, no
+// barrier, no LDS): a small cloud is a short dependent chain -- row range -> parent -> pooled gradient -> sums -> write -- and four
+// independent waves per cloud run four such chains where a 256-thread workgroup per slice ran one (level 2 of cfg2: 29 rows per cloud).
+template <int RL, int CACHE, int CL, bool WAVE>
+__device__ __forceinline__ void arp_inorm_bwd_slice(const f32x4* __restrict__ g_pool, const int4* __restrict__ arg, const int* __restrict__ parent,
+                                                    const f32x4* __restrict__ xhat, const f32x4* __restrict__ inv_std, const f32x4* __restrict__ w,
+                                                    const f32x4* __restrict__ bias, const int* __restrict__ cloud_group, f32x4* __restrict__ dY,
+                                                    f32x4* __restrict__ ga_out, const f32x4* __restrict__ ga_prev, const f32x4* __restrict__ gw_extra,
+                                                    f32x4* __restrict__ part, f32x4* s_red, int b, int r0, int r1, int c4, int rl) {
     const int n = r1 - r0;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4* ga_out = (ga_clouds <= 0 || b < ga_clouds) ? ga_out_all : nullptr;  // only the leading clouds keep their masked gradient
-    if (n <= 0) {
-        if (part && rl == 0) {
-            part[((int64_t)b * 2 + 0) * 32 + c4] = zero;
-            part[((int64_t)b * 2 + 1) * 32 + c4] = zero;
-        }
-        return;
-    }
     const f32x4 ww = w[c4], bb = bias[c4];
     const f32x4 is = inv_std[(int64_t)b * 32 + c4];  // issued with the first loads, not after the reductions (one round trip less)
     f32x4 ex = zero;
@@ -447,23 +438,28 @@ __global__ __launch_bounds__(RL * CL) void k_arp_inorm_bwd(const f32x4* __restri
         s1 += gx;
         s2 += gx * xh;
     }
-    f32x4 m1, m2;
-    if (part) {  // all four column sums in one exchange (part is a kernel argument: the branch is uniform)
-        f32x4 v[4] = {s1, s2, sw, sb};
+    f32x4 v[4] = {s1, s2, sw, sb};
+    if (WAVE) {  // fold the 8 row-lanes of the wave (lane = row-lane * 8 + channel-lane): fixed butterfly order
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[q][j] += __shfl_xor(v[q][j], o, 64);
+    } else if (part) {  // all four column sums in one exchange (part is a kernel argument: the branch is uniform)
         cloud_colsums<RL, CL, 4>(v, s_red);
-        m1 = v[0] / (float)n;
-        m2 = v[1] / (float)n;
-        if (rl == 0) {
-            part[((int64_t)b * 2 + 0) * 32 + c4] = v[2];
-            part[((int64_t)b * 2 + 1) * 32 + c4] = v[3];
-        }
     } else {
-        f32x4 v[2] = {s1, s2};
-        cloud_colsums<RL, CL, 2>(v, s_red);
-        m1 = v[0] / (float)n;
-        m2 = v[1] / (float)n;
+        f32x4 v2[2] = {s1, s2};
+        cloud_colsums<RL, CL, 2>(v2, s_red);
+        v[0] = v2[0];
+        v[1] = v2[1];
     }
-    #pragma unroll
+    const f32x4 m1 = v[0] / (float)n, m2 = v[1] / (float)n;
+    if (part && rl == 0) {
+        part[((int64_t)b * 2 + 0) * 32 + c4] = v[2];
+        part[((int64_t)b * 2 + 1) * 32 + c4] = v[3];
+    }
+#pragma unroll
     for (int i = 0; i < CACHE; ++i) {
         const int r = r0 + rl + i * RL;
         if (r < r1) dY[(int64_t)r * 32 + c4] = (vg[i] - vx[i] * m2 - m1) * is;
@@ -473,6 +469,48 @@ __global__ __launch_bounds__(RL * CL) void k_arp_inorm_bwd(const f32x4* __restri
         row(r, xh, ga, gx);
         dY[(int64_t)r * 32 + c4] = (gx - xh * m2 - m1) * is;
     }
+}
+
+// Backward of pool -> ReLU -> affine -> instance norm in ONE pass over a cloud (k_arp_bwd followed by k_inorm_bwd, without the
+// round trip of g_xhat through HBM): the thread's rows of g_xhat and xhat stay in registers between the statistics and the final
+// write.  Per-cloud partial sums of ga*xhat / ga go to part[b][2][32]; k_cloud_group_sum folds them per group in cloud order.
+// grid (cloud, 32 / CL): a workgroup takes CL float4 channel-lanes (CL * 16 B of every row), so several workgroups per CU overlap
+// their gather latencies (CL = 8: 128-B pieces of a row, one cache line).  Clouds of at most WAVE_ROWS rows are taken by workgroup
+// (cloud, 0) alone, one wave per channel slice (see arp_inorm_bwd_slice); the choice depends on the cloud's row count only, so a bound-sized
+// launch and an exact one sum in the same order.
+constexpr int ARP_WAVE_CACHE = 6;    // rows per lane kept in registers in wave mode (8 row-lanes: 48 rows; longer clouds re-read their tail from L2)
+constexpr int ARP_WAVE_ROWS = 128;   // clouds up to this many rows go wave by wave (measured at cfg2: 65.6 -> 30.8 us at level 2, 101 -> 88 us at level 1)
+template <int RL, int CACHE, int CL>
+__global__ __launch_bounds__(RL * CL) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_arp_inorm_bwd(const f32x4* __restrict__ g_pool, const int4* __restrict__ arg, const int* __restrict__ parent,
+                                                           const f32x4* __restrict__ xhat, const f32x4* __restrict__ inv_std,
+                                                           const f32x4* __restrict__ w, const f32x4* __restrict__ bias,
+                                                           const int* __restrict__ seg_off, const int* __restrict__ cloud_group,
+                                                           f32x4* __restrict__ dY, f32x4* __restrict__ ga_out_all, int ga_clouds,
+                                                           const f32x4* __restrict__ ga_prev, const f32x4* __restrict__ gw_extra,
+                                                           f32x4* __restrict__ part /*[B][2][32] or null*/, int wave_rows) {
+    static_assert(RL * CL == 256 && CL == 8, "four slices of eight float4 channel-lanes");
+    __shared__ f32x4 s_red[4 * (RL * CL / 64) * CL];
+    const int b = blockIdx.x;
+    const int r0 = seg_off[b], r1 = seg_off[b + 1];
+    const int n = r1 - r0;
+    f32x4* ga_out = (ga_clouds <= 0 || b < ga_clouds) ? ga_out_all : nullptr;  // only the leading clouds keep their masked gradient
+    if (n <= 0) {
+        const int c4 = blockIdx.y * CL + threadIdx.x % CL, rl = threadIdx.x / CL;
+        if (part && rl == 0) {
+            part[((int64_t)b * 2 + 0) * 32 + c4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            part[((int64_t)b * 2 + 1) * 32 + c4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        return;
+    }
+    if (n <= wave_rows) {  // small cloud: one wave per channel slice, all four slices in workgroup (cloud, 0)
+        if (blockIdx.y) return;
+        const int lane = threadIdx.x & 63;
+        arp_inorm_bwd_slice<8, ARP_WAVE_CACHE, 8, true>(g_pool, arg, parent, xhat, inv_std, w, bias, cloud_group, dY, ga_out, ga_prev, gw_extra, part, s_red, b,
+                                                           r0, r1, (threadIdx.x >> 6) * 8 + (lane & 7), lane >> 3);
+        return;
+    }
+    arp_inorm_bwd_slice<RL, CACHE, CL, false>(g_pool, arg, parent, xhat, inv_std, w, bias, cloud_group, dY, ga_out, ga_prev, gw_extra, part, s_red, b, r0, r1,
+                                              blockIdx.y * CL + threadIdx.x % CL, threadIdx.x / CL);
 }
 
 // out_w/out_b[g][c4] = sum over the clouds of group g of part[b][0/1][c4]; 16 cloud-lanes take clouds in order (a short dependent
@@ -632,13 +670,14 @@ DD3D_API int dd3d_arp_inorm_bwd(const float* g_pool, const int32_t* arg, const i
         return DD3D_EARG;
     if (gw_w && (ws_bytes < dd3d_arp_inorm_bwd_ws_bytes(B) || !ws)) return DD3D_EWS;
     hipStream_t st = (hipStream_t)stream;
+    static const int wave_rows = getenv("DD3D_ARP_WAVE_ROWS") ? atoi(getenv("DD3D_ARP_WAVE_ROWS")) : ARP_WAVE_ROWS;  // 0: every cloud in workgroup mode (measurements)
     if (B > 0) {
         if (!g_pool || !arg || !parent || !xhat || !inv_std || !seg_off || !dY) return DD3D_EARG;
         // 32 row-lanes x 8 float4 channel-lanes per workgroup, four workgroups per cloud (measured against 512- and 1024-thread shapes:
         // more, smaller workgroups per CU overlap their gather chains best)
         k_arp_inorm_bwd<32, 4, 8><<<dim3(B, 4), 256, 0, st>>>((const f32x4*)g_pool, (const int4*)arg, parent, (const f32x4*)xhat, (const f32x4*)inv_std,
                                                        (const f32x4*)w, (const f32x4*)b, seg_off, cloud_group, (f32x4*)dY, (f32x4*)ga_out, ga_clouds,
-                                                       (const f32x4*)ga_prev, (const f32x4*)gw_extra, gw_w ? (f32x4*)ws : nullptr);
+                                                       (const f32x4*)ga_prev, (const f32x4*)gw_extra, gw_w ? (f32x4*)ws : nullptr, wave_rows);
     }
     if (gw_w) k_cloud_group_sum<<<dim3(G), 1024, 0, st>>>((const f32x4*)ws, group_cloud_off, (f32x4*)gw_w, (f32x4*)gw_b);
     DD3D_CHECK_LAUNCH();

@@ -38,6 +38,7 @@ J, S = 10, 784
 Wc = R(J, 128 * S) * .01
 Wsm = site_major(Wc, 128, S); sst = _site_strides(J, 128, S)
 logits, dl = torch.empty(B, J, device=dev), R(B, J)
+gP1 = R(M2, 128)
 gP0, gY0, gY1, dW1, dW0 = R(M1, 128), torch.empty(M0, 128, device=dev), R(M1, 128), torch.empty(G, 27, 128, 128, device=dev), torch.empty(G, 27, 3, 128, device=dev)
 gw_w, gw_b = torch.empty(G, 128, device=dev), torch.empty(G, 128, device=dev)
 st = L.stream()
@@ -58,6 +59,8 @@ K = {
  "sl_bwd_x": (lambda: sl_bwd_x_call(dl, dp, None, Wsm, sst, J, 0, P1), 512 * M2 * (1 + J)),
  "arp_inorm_bwd L1": (lambda: L.call("dd3d_arp_inorm_bwd", L.ptr(gP0), L.ptr(arg0), L.ptr(cm.parent(2)), L.ptr(xh0), L.ptr(is0), L.ptr(w), L.ptr(bb), 128, L.ptr(seg1), B,
                                      L.ptr(cg), L.ptr(gco), G, L.ptr(gY0), None, 0, None, None, L.ptr(gw_w), L.ptr(gw_b), L.ptr(ws), ws.numel(), st), 1024 * M0 + 1024 * M1),
+ "arp_inorm_bwd L2": (lambda: L.call("dd3d_arp_inorm_bwd", L.ptr(gP1), L.ptr(arg1), L.ptr(cm.parent(4)), L.ptr(xh1), L.ptr(is1), L.ptr(w), L.ptr(bb), 128, L.ptr(seg2), B,
+                                     L.ptr(cg), L.ptr(gco), G, L.ptr(gY1), None, 0, None, None, L.ptr(gw_w), L.ptr(gw_b), L.ptr(ws), ws.numel(), st), 1024 * M1 + 1024 * M2),
  "conv128_bww": (lambda: L.call("dd3d_conv_bwd_weight", L.ptr(P0), 128, L.ptr(gY1), 128, L.ptr(k1), ld1, 27, M1, L.ptr(gro2), G, L.ptr(dW1), L.ptr(ws), ws.numel(), st), 0),
  "conv128_bww_clouds": (lambda: L.call("dd3d_conv128_bwd_weight_clouds", L.ptr(P0), L.ptr(gY1), L.ptr(k1), ld1, 27, M1, L.ptr(seg2), B, L.ptr(gro2), G, L.ptr(dW1), L.ptr(cm.err), L.ptr(ws), ws.numel(), st), 0),
  "conv3_bww": (lambda: L.call("dd3d_conv_bwd_weight", L.ptr(F0), 3, L.ptr(gY0), 128, L.ptr(k0), ld0, 27, M0, L.ptr(gro1), G, L.ptr(dW0), L.ptr(ws), ws.numel(), st), 512 * M0 + 120 * M0),
