@@ -378,11 +378,6 @@ __global__ __launch_bounds__(256) void k_arp_reduce(const f32x4* __restrict__ pa
     }
 }
 
-// Backward of pool -> ReLU -> affine -> instance norm in ONE pass over a cloud (k_arp_bwd followed by k_inorm_bwd, without the
-// round trip of g_xhat through HBM): the thread's rows of g_xhat and xhat stay in registers between the statistics and the final
-// write.  Per-cloud partial sums of ga*xhat / ga go to part[b][2][32]; k_cloud_group_sum folds them per group in cloud order.
-// grid (cloud, 32 / CL): a workgroup takes CL float4 channel-lanes (CL * 16 B of every row), so several workgroups per CU overlap
-// their gather latencies (CL = 8: 128-B pieces of a row, one cache line)
 // One cloud x one channel slice.  WAVE = false: the slice belongs to a workgroup of RL row-lanes x CL float4 channel-lanes (column sums through
 // LDS, two barriers).  WAVE = true: the slice belongs to ONE wave of 8 row-lanes x 8 channel-lanes (column sums by three shuffle steps, no
 // barrier, no LDS): a small cloud is a short dependent chain -- row range -> parent -> pooled gradient -> sums -> write -- and four
@@ -514,11 +509,12 @@ __global__ __launch_bounds__(RL * CL) __attribute__((amdgpu_waves_per_eu(4, 8)))
 }
 
 // out_w/out_b[g][c4] = sum over the clouds of group g of part[b][0/1][c4]; 16 cloud-lanes take clouds in order (a short dependent
-// chain of L2 reads each), combined in lane order: deterministic
-__global__ __launch_bounds__(1024) void k_cloud_group_sum(const f32x4* __restrict__ part, const int* __restrict__ group_cloud_off, f32x4* __restrict__ gw_w,
-                                                          f32x4* __restrict__ gw_b) {
-    __shared__ f32x4 s_red[1024];
-    const int g = blockIdx.x, c4 = threadIdx.x & 31, j = (threadIdx.x >> 5) & 1, sl = threadIdx.x >> 6;
+// chain of L2 reads each), combined in lane order: deterministic.  grid (group, 4 channel slices) of 256-thread workgroups: a
+// 1024-thread workgroup needs a quarter of a CU's wave slots at once and waited ~70 us for them next to the 128-channel kernel gradient.
+__global__ __launch_bounds__(256) void k_cloud_group_sum(const f32x4* __restrict__ part, const int* __restrict__ group_cloud_off, f32x4* __restrict__ gw_w,
+                                                         f32x4* __restrict__ gw_b) {
+    __shared__ f32x4 s_red[256];
+    const int g = blockIdx.x, c4 = blockIdx.y * 8 + (threadIdx.x & 7), j = (threadIdx.x >> 3) & 1, sl = threadIdx.x >> 4;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     int b = group_cloud_off[g] + sl;
     const int b1 = group_cloud_off[g + 1];
@@ -535,7 +531,7 @@ __global__ __launch_bounds__(1024) void k_cloud_group_sum(const f32x4* __restric
     if (sl == 0) {
         f32x4 t = s_red[threadIdx.x];
 #pragma unroll 4
-        for (int q = 1; q < 16; ++q) t += s_red[threadIdx.x + 64 * q];
+        for (int q = 1; q < 16; ++q) t += s_red[threadIdx.x + 16 * q];
         (j == 0 ? gw_w : gw_b)[(int64_t)g * 32 + c4] = t;
     }
 }
@@ -679,7 +675,7 @@ DD3D_API int dd3d_arp_inorm_bwd(const float* g_pool, const int32_t* arg, const i
                                                        (const f32x4*)w, (const f32x4*)b, seg_off, cloud_group, (f32x4*)dY, (f32x4*)ga_out, ga_clouds,
                                                        (const f32x4*)ga_prev, (const f32x4*)gw_extra, gw_w ? (f32x4*)ws : nullptr, wave_rows);
     }
-    if (gw_w) k_cloud_group_sum<<<dim3(G), 1024, 0, st>>>((const f32x4*)ws, group_cloud_off, (f32x4*)gw_w, (f32x4*)gw_b);
+    if (gw_w) k_cloud_group_sum<<<dim3(G, 4), 256, 0, st>>>((const f32x4*)ws, group_cloud_off, (f32x4*)gw_w, (f32x4*)gw_b);
     DD3D_CHECK_LAUNCH();
     return 0;
 }
