@@ -43,7 +43,7 @@ class KernelTimer:
                 e0.record()
                 orig(name, *args)
                 e1.record()
-                timer.records.append((e0, e1, args))
+                timer.records.append((name, e0, e1, args))
             else:
                 orig(name, *args)
 
@@ -119,8 +119,12 @@ def main():
         d = FusedDistiller(images_all, indices_class, net, graph=(args.path == "graph"), **kw)
 
     # ---- live timing of the dominant kernel: the Cin=128 sparse convolution forward (fp32 MFMA) ----
-    timer = KernelTimer({"dd3d_conv_fwd": lambda a: a[2] == 128 and a[10] == 0,        # Cin = 128, not mirrored
-                         "dd3d_conv128_ordered": lambda a: a[8] == 0})                  # the scheduled launch of the same kernel
+    BIG = 65536   # rows from which the 128-channel launches run k_conv128_rows<4> (dd3d_conv_schedule_tile_rows)
+    timer = KernelTimer({"dd3d_conv_fwd": lambda a: True,                               # Cin = 128 launches and the first layer (Cin = 3)
+                         "dd3d_conv128_ordered": lambda a: True,                        # forward (a[8] == 0) and mirrored = backward-data launch
+                         "dd3d_conv_bwd_data": lambda a: a[5] == 128,
+                         "dd3d_inorm_arp_fwd": lambda a: True,
+                         "dd3d_arp_inorm_bwd": lambda a: a[18] is not None})            # the first-order launches (they also reduce the affine gradients)
     nbr_keep = []
     orig_apply_fwd = _ops.SparseConvFn.forward
 
@@ -171,21 +175,44 @@ def main():
         timer.on = False
 
     if rank == 0:
-        ms = [e0.elapsed_time(e1) for (e0, e1, _a) in timer.records]
+        rec = [(name, e0.elapsed_time(e1), a) for (name, e0, e1, a) in timer.records]
+        # (rows, mirrored?, ms) of every Cin = 128 launch; the roofline kernel's launches are those over the merged batch (the largest row
+        # bound): one forward and one mirrored (backward-data) launch per step.  The second-order launch over the synthetic rows is smaller.
+        conv = []
+        for (n, t, a) in rec:
+            if n == "dd3d_conv128_ordered":
+                conv.append((int(a[6]), bool(a[8]), t, True))
+            elif n == "dd3d_conv_fwd" and a[2] == 128:
+                conv.append((int(a[8]), bool(a[10]), t, False))
+            elif n == "dd3d_conv_bwd_data":
+                conv.append((int(a[1]), True, t, False))
+        Mf = max([c[0] for c in conv], default=0)
+        conv = [c for c in conv if c[0] == Mf]
+        fwd, mir = [c[2] for c in conv if not c[1]], [c[2] for c in conv if c[1]]
+        ms = fwd + mir
         pairs += [int((nbr[:, :M] >= 0).sum().item()) for (nbr, M) in nbr_keep]
-        flops = [2.0 * p * 128 * 128 for p in pairs]
+        avg_pairs = sum(pairs) / max(len(pairs), 1)
         avg_ms = sum(ms) / max(len(ms), 1)
-        avg_flop = sum(flops) / max(len(flops), 1)
-        roof = {"bound": "mfma", "kernel": "k_conv128_rows<4> (forward of the Cin=Cout=128 convolution on the merged batch, scheduled launch dd3d_conv128_ordered, fp32 MFMA 32x32x2)", "achieved": avg_flop / (avg_ms * 1e-3) / 1e12,
-                "peak": 157.3, "unit": "TFLOP/s", "traffic": None, "launches": len(ms), "avg_launch_us": avg_ms * 1e3,
-                "avg_pairs_per_launch": sum(pairs) / max(len(pairs), 1)}
-        roof["frac"] = roof["achieved"] / roof["peak"]
+        avg_flop = 2.0 * avg_pairs * 128 * 128
+        mean = lambda v: sum(v) / max(len(v), 1)
+        scheduled = any(c[3] for c in conv)
+        tile_rows = 128 if Mf >= BIG else 32
+        kname = ("k_conv128_rows<4>" if tile_rows == 128 else "k_conv128<32,1,4>") + (
+            " (Cin=Cout=128 convolution on the merged batch, forward and mirrored = backward-data launches, " +
+            ("scheduled launch dd3d_conv128_ordered" if scheduled else "plain launch dd3d_conv_fwd") + ", fp32 MFMA 32x32x2)")
+        roof = {"bound": "mfma", "kernel": kname, "achieved": avg_flop / (avg_ms * 1e-3) / 1e12 if ms else None,
+                "peak": 157.3, "unit": "TFLOP/s", "traffic": None, "traffic_measured_in_run": False, "launches": len(ms), "avg_launch_us": avg_ms * 1e3,
+                "avg_launch_us_forward": mean(fwd) * 1e3, "avg_launch_us_mirrored": mean(mir) * 1e3, "avg_pairs_per_launch": avg_pairs,
+                "timing": "HIP events on the launching stream around every launch of the kernel, over the steps enqueued eagerly after the timed "
+                          "graph replays (identical kernels, arguments and launch bounds); both launches of a step count"}
+        roof["frac"] = roof["achieved"] / roof["peak"] if ms else None
         # HBM bytes per launch of this kernel: PMC counters cannot be read from inside the process, so the figure comes from the
-        # committed rocprofv3 --pmc passes of this same command (tools/pmc.sh -> tools/pmc_to_json.py), corrected as the file says
+        # committed rocprofv3 --pmc passes of this same command (tools/pmc.sh -> tools/pmc_to_json.py), corrected as the file says;
+        # only attached to the run it was measured on (one GPU, all classes, default ipc)
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv128_rows.json")
-        if args.path != "dropin" and args.config == "cfg2" and args.ipc == IPC and os.path.exists(pmc):
+        if args.path != "dropin" and args.config == "cfg2" and args.ipc == IPC and world == 1 and not args.emulate_shard and tile_rows == 128 and os.path.exists(pmc):
             roof["traffic"] = json.load(open(pmc))["traffic_bytes_per_launch"]
-            roof["traffic_source"] = "profiles/r01_pmc_conv128_rows.json"
+            roof["traffic_source"] = "profiles/r01_pmc_conv128_rows.json (rocprofv3 --pmc passes of this command, not this run)"
         step_work = None
         if args.path != "dropin":
             # the counts the algorithmic work of a step follows from (merged batch of the last step of this rank) and the
@@ -198,6 +225,28 @@ def main():
             ncls = len(d.classes)
             flop = 3 * (2.0 * P0 * 3 * 128 + 2.0 * P1 * 128 * 128 + 2.0 * M2 * 128 * n_classes)
             step_s = dt / args.steps
+            # BASELINE.json's metric also asks for the achieved HBM GB/s of the bandwidth kernels: algorithmic bytes over the
+            # same event timings, per kernel family, averaged over the eagerly enqueued steps
+            fam = {}
+            def add(key, t_ms, nbytes):
+                f = fam.setdefault(key, [0.0, 0.0])
+                f[0] += t_ms
+                f[1] += nbytes
+            lv = 0
+            for (n, t, a) in rec:
+                if n == "dd3d_inorm_arp_fwd":
+                    mi, mo = ((M0, M1), (M1, M2))[lv % 2]
+                    add("instance norm + affine + ReLU + max-pool forward (k_inorm_arp_fwd)", t, 1024.0 * mi + 1024.0 * mo)
+                    lv += 1
+                elif n == "dd3d_conv_fwd" and a[2] == 3:
+                    add("first-layer convolution forward (k_conv3_fwd)", t, 4.0 * (3 * M0 + 128 * M0) + 8.0 * P0 + 4 * 27 * 3 * 128)
+            lv = 0
+            for (n, t, a) in rec:
+                if n == "dd3d_arp_inorm_bwd":
+                    mi, mo = ((M1, M2), (M0, M1))[lv % 2]
+                    add("pool + ReLU + affine + instance norm backward (k_arp_inorm_bwd)", t, 1024.0 * mi + 1024.0 * mo)
+                    lv += 1
+            hbm = {k: {"GB_per_s": v[1] / (v[0] * 1e-3) / 1e9, "frac_of_8TBps": v[1] / (v[0] * 1e-3) / 8e12} for k, v in fam.items() if v[0] > 0}
             step_work = {"N_bound": int(ps.N), "M0": M0, "M1": M1, "M2": M2, "P0": P0, "P1": P1, "classes_on_rank": ncls, "flop_algorithmic": flop,
                          "formula": "3*(2*P0*3*128 + 2*P1*128*128 + 2*M2*128*n_cls)", "tflops_whole_step": flop / step_s / 1e12}
         out = {"metric": METRIC, "value": args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -209,9 +258,20 @@ def main():
                                                "parallelism": f"class-sharded x{world}",
                                                "path": {"graph": "class-batched step, one HIP graph replay per step", "fused": "class-batched step, eager launches",
                                                         "dropin": "drop-in autograd loop"}[args.path]},
-               "loss": loss_value, "roofline": roof, "step_work": step_work}
+               "loss": loss_value, "roofline": roof, "step_work": step_work, "hbm": hbm if args.path != "dropin" else None}
         if not args.no_cpu_baseline and world == 1:
+            # the reference-shaped loop (the Distiller of dd3d_amd/mnist_distill.py: per-class autograd, what "loop body unchanged" means in
+            # INTEGRATION.md) on the same workload, 3 steps after 1 warm-up, beside the class-batched graph step that `value` reports
+            dd = Distiller(images_all, indices_class, net, **kw)
+            dd.outer_step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                dd.outer_step()
+            torch.cuda.synchronize()
+            out["dropin_ms_per_step"] = (time.perf_counter() - t0) / 3 * 1e3
             out["cpu_baseline"] = cpu_baseline(images_all, indices_class, net, syn, args)
+            out["cpu_baseline_pytorch"] = cpu_baseline_pytorch(images_all, indices_class, args)
         print(json.dumps(out), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
@@ -240,6 +300,33 @@ def cpu_baseline(images_all, indices_class, net, syn, args):
             t += time.perf_counter() - t0
     return {"value": nsteps / t, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{nsteps} full steps of the same workload after 1 warm-up step, {t:.1f} s of CPU work"}
+
+
+def cpu_baseline_pytorch(images_all, indices_class, args):
+    """BASELINE.json configs[0] on the host cores: the reference's ``--pytorch`` path (MEPytorch: sparse() -> dense -> Conv3d stack, full
+    second order; models/MEConv.py:166-207) as restated in oracle/ref_model.py, 10 classes x 256 real clouds, 1 synthetic cloud per class.
+    One untimed warm-up step, then 6 timed steps (SURVEY.md section 6 measured 9.5-20.7 s/step for the reference's own file on 8 cores)."""
+    from oracle import ref_model as R
+    import numpy as np
+    from dd3d_amd.synthetic import init_synthetic
+    torch.manual_seed(0)
+    onet = R.MEPytorch(3, 10)
+    rng = np.random.RandomState(1234)
+    osyn = init_synthetic(NUM_CLASSES, 1, NUM_POINTS, seed=0)
+    osyn.requires_grad_()
+    opt = torch.optim.SGD([osyn], lr=0.1, momentum=0.5)
+    nsteps, t = 6, 0.0
+    for it in range(nsteps + 1):
+        reals = [images_all[rng.permutation(indices_class[c])[:REAL_PER_CLASS]] for c in range(NUM_CLASSES)]
+        osyn.requires_grad_(False)
+        R.clamp_synthetic_(osyn)
+        osyn.requires_grad_()
+        t0 = time.perf_counter()
+        R.matching_step(onet, osyn, reals, 1, args.metric_name, True, optimizer=opt)
+        if it > 0:
+            t += time.perf_counter() - t0
+    return {"value": nsteps / t, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port", "workload": "cfg1: MEPytorch (--pytorch), ipc=1",
+            "sample": f"{nsteps} full steps after 1 warm-up step, {t:.1f} s of CPU work"}
 
 
 if __name__ == "__main__":

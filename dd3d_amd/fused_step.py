@@ -355,6 +355,33 @@ class _GradList(list):
         return (self[i] for i in range(len(self)))
 
 
+class _SgdState:
+    """``optimizer_img`` of the reference loop (mnist_distill.py:303: SGD([image_syn], lr, momentum=0.5)) as the fused step keeps it -- a
+    momentum buffer updated inside dd3d_sgd_scatter -- with torch.optim.SGD's ``state_dict`` layout, so checkpoints written from the fused
+    path carry the reference's ``optimizer_state_dict`` (mnist_distill.py:394) and load into a torch SGD in either code base."""
+
+    def __init__(self, owner):
+        self._o = owner
+
+    def state_dict(self):
+        o = self._o
+        ref = torch.optim.SGD([torch.zeros(1, requires_grad=True)], lr=o.lr, momentum=o.momentum).state_dict()   # this torch's group keys
+        state = {0: {"momentum_buffer": o.momentum_buf.clone()}} if o.steps_done > 0 else {}
+        return {"state": state, "param_groups": ref["param_groups"]}
+
+    def load_state_dict(self, sd):
+        o = self._o
+        g = sd["param_groups"][0]
+        o.lr, o.momentum = float(g["lr"]), float(g["momentum"])
+        buf = sd.get("state", {}).get(0, {}).get("momentum_buffer")
+        if buf is None:
+            o.momentum_buf.zero_()
+        else:
+            o.momentum_buf.copy_(buf.to(o.momentum_buf.device))
+        if o._graph is not None:
+            raise RuntimeError("load the optimizer state before the first captured step (lr / momentum are baked into the graph)")
+
+
 class FusedDistiller:
     """Same constructor and state as ``mnist_distill.Distiller`` (MEConvExp only); ``outer_step`` runs the class-batched path.
 
@@ -390,6 +417,8 @@ class FusedDistiller:
             image_syn = 28 * torch.rand((num_classes * ipc, num_points, 3), generator=g, dtype=torch.float)
         self.image_syn = image_syn.to(dev).clone().contiguous()
         self.momentum_buf = torch.zeros_like(self.image_syn)
+        self.label_syn = torch.arange(num_classes, device=dev).repeat_interleave(ipc)   # mnist_distill.py:297
+        self.optimizer_img = _SgdState(self)
         self.lr, self.momentum, self.steps_done = dist_lr, momentum, 0
         G = self.G = len(self.classes)
         cls = torch.tensor(self.classes, device=dev)
@@ -410,7 +439,26 @@ class FusedDistiller:
         self.stream_data, self._prefetched = torch.cuda.Stream(dev), None
         self.use_graph = bool(graph) and G > 0
         self._graph = self._static = None
+        self._graph_stamp, self._needs_eager = None, False
         self._scope = "graph%x" % id(self)
+
+    def _param_stamp(self):
+        """(address, version) of every network parameter: what the captured graph and its cached weight layouts were built from."""
+        return tuple((p.data_ptr(), p._version) for p in self.network.parameters())
+
+    def invalidate(self):
+        """Drop the captured graph and the cached weight layouts (transposed 128-channel kernel, site-major classifier weight).  Called
+        automatically when a parameter's address or version counter changed since the capture; call it yourself after editing weights
+        through ``.data`` (which bumps no version counter).  The next step runs eagerly and rebuilds the layouts, the one after re-captures."""
+        self._graph = None
+        self._needs_eager = True
+        for p in self.network.parameters():
+            for attr in ("_dd3d_csm", "_dd3d_wt", "_dd3d_sm"):
+                if hasattr(p, attr):
+                    try:
+                        delattr(p, attr)
+                    except Exception:
+                        pass
 
     def _real_range(self):
         """(lo[3], hi[3]) of the real points before quantisation (one read-back, cached)."""
@@ -667,9 +715,12 @@ class FusedDistiller:
             if self._static is None:
                 self._build_static()
             self._upload_ids()
-            if force_eager or self.steps_done == 0:
+            if self._graph is not None and self._param_stamp() != self._graph_stamp:
+                self.invalidate()   # a weight changed (load_state_dict, optimizer step): the captured graph reads stale cached layouts
+            if force_eager or self.steps_done == 0 or self._needs_eager:
                 # the first step runs eagerly: it sizes the workspaces and builds the cached weight layouts the graph will reuse
                 loss = self._static_body()
+                self._needs_eager = False
             else:
                 if self._graph is None:
                     self._graph = torch.cuda.CUDAGraph()
@@ -678,6 +729,7 @@ class FusedDistiller:
                     with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
                         self._graph_loss = self._static_body()
                     self._graph_last = self.last
+                    self._graph_stamp = self._param_stamp()
                 self._graph.replay()
                 loss, self.last = self._graph_loss, self._graph_last
             self.steps_done += 1
@@ -690,6 +742,9 @@ class FusedDistiller:
         elif self._prefetched is not None:
             rb, self._prefetched = self._prefetched, None
             main.wait_stream(self.stream_data)
+            for t in rb.values():   # allocated on the data stream, consumed on the main one
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(main)
         else:
             rb = self.sample_real()
         xyz = self.image_syn[self.syn_rows].reshape(-1, 3)

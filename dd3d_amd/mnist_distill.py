@@ -99,9 +99,11 @@ class Distiller:
         return loss.detach()
 
 
-def main(argv=None):
+def main(argv=None, ini_path="configs/default.ini"):
     """The reference's ``__main__`` (mnist_distill.py:251-410) on MNIST-shaped synthetic digits: matching steps, the evaluation block at
-    the reference's iterations (:276, :320-330), checkpoint + .ply export every ``save_cad_every`` iterations (:383-402)."""
+    the reference's iterations (:276, :320-330), checkpoint + .ply export every ``save_cad_every`` iterations (:383-402).
+    MEConvExp runs on the class-batched HIP-graph step (``FusedDistiller``, the path ``bench.py`` times); ``--pytorch`` (MEPytorch) keeps the
+    autograd loop.  Two optional INI keys beyond the reference's, for short runs: [DISTILLATION] eval_epochs (1000) and num_eval (5)."""
     import copy
     import math
     import os
@@ -110,7 +112,7 @@ def main(argv=None):
     from .models.MNIST import ConvNet
     from .synthetic import mnist3d_like
     from .utils.Mnist2D import TensorDataset
-    settings.init(argv)
+    settings.init(argv, ini_path)
     dev = settings.device
     torch.random.manual_seed(int(time.time() * 1000) % 100000)
     images_all, _labels, indices_class = mnist3d_like(10, 512, seed=0)
@@ -118,9 +120,13 @@ def main(argv=None):
     testloader = torch.utils.data.DataLoader(TensorDataset(test_images.reshape(-1, 1, 28, 28), test_labels), batch_size=256, shuffle=False)
     network = MEPytorch(3, 10) if settings.Pyt else MEConvExp(in_channel=3, out_channel=10)
     settings.log_string(network)
-    d = Distiller(images_all, indices_class, network, ipc=settings.cad_per_class, num_points=settings.num_points,
-                  batch_size=settings.modelconfig.getint("batch_size"), dist_opt=settings.modelconfig.get("dist_opt"),
-                  dist_lr=settings.modelconfig.getfloat("dist_lr"), device=dev)
+    from .fused_step import FusedDistiller
+    make = Distiller if settings.Pyt else FusedDistiller
+    d = make(images_all, indices_class, network, ipc=settings.cad_per_class, num_points=settings.num_points,
+             batch_size=settings.modelconfig.getint("batch_size"), dist_opt=settings.modelconfig.get("dist_opt"),
+             dist_lr=settings.modelconfig.getfloat("dist_lr"), device=dev)
+    eval_epochs = settings.distillationconfig.getint("eval_epochs", fallback=1000)
+    num_eval = settings.distillationconfig.getint("num_eval", fallback=5)
     total = settings.distillationconfig.getint("total_iterations")
     eval_iteration_pool = [0, 250, total // 4, total // 2, total // 4 + total // 2, total - 1]
     export_cad_dir = os.path.join(settings.logging_folder_name, settings.distillationconfig.get("export_folder_name"))
@@ -132,10 +138,10 @@ def main(argv=None):
         if iteration in eval_iteration_pool:
             d.clamp()
             settings.log_string("----- Evaluation -----\nModel_train = Convnet2D\nIteration: " + str(iteration))
-            for it_eval in range(5):
+            for it_eval in range(num_eval):
                 classifier_network = ConvNet(1, 10, 128, 3, "relu", "instancenorm", "avgpooling")
                 evaluation.evaluate_synset(it_eval, classifier_network, copy.deepcopy(d.image_syn.detach()), copy.deepcopy(d.label_syn),
-                                           testloader, iteration, export_cad_dir=export_cad_dir)
+                                           testloader, iteration, Epoch=eval_epochs, export_cad_dir=export_cad_dir)
         loss = d.outer_step()
         log_loss.append(loss.item() / 10)
         if iteration % 100 == 0:
@@ -150,6 +156,7 @@ def main(argv=None):
                 export.save_checkpoint(savepath, iteration, least_loss, network, d.optimizer_img, d.image_syn, d.label_syn)
             settings.log_string("Exporting Point Cloud")
             settings.save_cad(d.image_syn, export_cad_dir, iteration, normalize=False)
+    return d
 
 
 if __name__ == "__main__":

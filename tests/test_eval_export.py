@@ -191,3 +191,31 @@ def test_evaluate_synset_runs_on_gpu(tmp_path):
         assert 0.0 <= acc_test <= 1.0 and acc_train >= 0.5
     finally:
         settings.device, settings.cad_per_class = old
+
+
+@pytest.mark.gpu
+def test_main_runs_the_fused_graph_path_with_eval_and_export(tmp_path):
+    """mnist_distill.main() end to end for a few iterations: MEConvExp goes through FusedDistiller (the HIP-graph step bench.py times),
+    the evaluation block and the .ply export run, and the checkpoint holds the reference's six keys with a torch-SGD optimizer state that
+    loads into torch.optim.SGD (mnist_distill.py:390-398)."""
+    from dd3d_amd import export, mnist_distill
+    from dd3d_amd.fused_step import FusedDistiller
+    ini = tmp_path / "t.ini"
+    ini.write_text("[DEFAULT]\nlogging_parent = %s\nexperiment_name = t\n[MODEL]\nbatch_size = 32\ndist_opt = modmse\ndist_lr = 0.1\n[SHAPENET]\nnum_points = 250\n"
+                   "[DISTILLATION]\ncad_per_class = 2\ntotal_iterations = 5\nsave_cad_every = 2\nexport_folder_name = output/\n"
+                   "distillation_checkpoint_dir = %s\neval_epochs = 2\nnum_eval = 1\n" % (tmp_path / "logs", tmp_path / "ckpt"))
+    d = mnist_distill.main(["--no-log"], str(ini))
+    assert isinstance(d, FusedDistiller) and d._graph is not None and d.steps_done == 5
+    d.check()
+    ck = list((tmp_path / "ckpt").glob("*.pth"))
+    assert len(ck) == 1
+    state = torch.load(str(ck[0]), weights_only=True)
+    assert list(state.keys()) == ["epoch", "least_loss", "model_state_dict", "optimizer_state_dict", "synthetic_xyz", "synthetic_labels"]
+    assert tuple(state["synthetic_xyz"].shape) == (20, 250, 3) and state["synthetic_labels"].tolist() == [c for c in range(10) for _ in range(2)]
+    p = state["synthetic_xyz"].clone().requires_grad_()
+    opt = torch.optim.SGD([p], lr=0.5, momentum=0.9)
+    opt.load_state_dict(state["optimizer_state_dict"])      # torch's own loader accepts it
+    assert opt.param_groups[0]["lr"] == 0.1 and opt.param_groups[0]["momentum"] == 0.5
+    assert tuple(opt.state_dict()["state"][0]["momentum_buffer"].shape) == (20, 250, 3)
+    plys = list((tmp_path / "logs").rglob("*.ply"))
+    assert len(plys) >= 20 and export.read_ply(str(plys[0])).shape == (250, 3)

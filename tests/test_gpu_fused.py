@@ -358,3 +358,27 @@ def test_cfg3_shaped_graph_step_vs_oracle():
     assert 10 * 50 * 250 > SPLIT_MAX_ROWS
     _graph_steps_vs_oracle(f, images, idx, np.random.RandomState(3), _oracle_net(), 50, 32, "modmse", 2)
     assert f._graph is not None
+
+
+def test_graph_follows_a_weight_change():
+    """The captured graph reads cached layouts of the frozen weights (transposed 128-channel kernel, site-major classifier weight).
+    load_state_dict bumps the parameters' version counters: the next step must drop the graph, rebuild the layouts and re-capture --
+    bitwise equal to an eager distiller that got the same weights at the same step."""
+    from dd3d_amd.fused_step import FusedDistiller
+    from dd3d_amd.synthetic import mnist3d_like
+    images, _, idx = mnist3d_like(3, 30, seed=5)
+    syn = init_synthetic(3, 2, 250, seed=2)
+    kw = dict(ipc=2, num_classes=3, batch_size=16, device=DEV, seed=4, image_syn=syn)
+    fg = FusedDistiller(images, idx, _net(), graph=True, **kw)
+    fe = FusedDistiller(images, idx, _net(), graph=False, **kw)
+    for _ in range(3):
+        assert fg.outer_step().item() == fe.outer_step().item()
+    assert fg._graph is not None
+    new = {k: v * 1.25 for k, v in det_state_dict(fg.network, "net.other").items()}
+    fg.network.load_state_dict(new)
+    fe.network.load_state_dict(new)
+    for step in range(4):
+        lg, le = fg.outer_step().item(), fe.outer_step().item()
+        assert lg == le, f"step {step} after the weight change: graph {lg} vs eager {le}"
+        assert torch.equal(fg.image_syn, fe.image_syn)
+    assert fg._graph is not None   # re-captured
