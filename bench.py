@@ -62,6 +62,7 @@ def main():
                          "cfg4 = 40 classes x 256 real ellipsoid-shell clouds x 1024 pts, voxel 0.05, ipc 10 (record runs, not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--emulate-shard", default="", help="R/W: time rank R's share of a W-rank job on this one GPU (no process group)")
+    ap.add_argument("--defer-loss", action="store_true", help="graph path: compute each step's loss VALUE next to the following step (measured slower: DESIGN.md section 3)")
     ap.add_argument("--path", default="graph", choices=["graph", "fused", "dropin"],
                     help="graph: class-batched step captured into one HIP graph (default); fused: the same step enqueued eagerly; "
                          "dropin: the reference-shaped autograd loop")
@@ -116,7 +117,7 @@ def main():
     if args.path == "dropin":
         d = Distiller(images_all, indices_class, net, **kw)
     else:
-        d = FusedDistiller(images_all, indices_class, net, graph=(args.path == "graph"), **kw)
+        d = FusedDistiller(images_all, indices_class, net, graph=(args.path == "graph"), defer_loss=(args.path == "graph" and args.defer_loss), **kw)
 
     # ---- live timing of the dominant kernel: the Cin=128 sparse convolution forward (fp32 MFMA) ----
     BIG = 65536   # rows from which the 128-channel launches run k_conv128_rows<4> (dd3d_conv_schedule_tile_rows)
@@ -159,6 +160,10 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = one_step()
+    if getattr(d, "defer", False):
+        # deferred-loss mode: every replay carried the loss-value work of the step before it; the last step's is completed here, INSIDE the
+        # timed region, so the K timed steps contain K times the whole work of a step
+        loss = reduce_loss(d.flush())
     sync_all()
     dt = time.perf_counter() - t0
     timer.on = False

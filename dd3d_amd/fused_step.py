@@ -41,6 +41,23 @@ def _empty(shape, dev, dtype=_F32):
     return torch.empty(shape, dtype=dtype, device=dev)
 
 
+def conv_kernel_gradient(X, Cin, dY, nbr, ld, M, gro, G, dev, seg=None, B=0, err=None):
+    """dW [G, 27, Cin, 128] of a stride-1 convolution on the current stream (one kernel gradient per group of rows)."""
+    dW = _empty((G, 27, Cin, 128), dev)
+    if Cin == 128 and seg is not None and os.environ.get("DD3D_BWW_CLOUDS", "0") != "0":
+        # small clouds: whole-cloud windows of both operands in LDS (conv_bww.hip).  Off by default: alone it takes what the row-chunk kernel
+        # and its slab sum take (243 + 10 us against 223 + 30 us at cfg2, with a quarter of the memory traffic), but its workgroups fill a
+        # CU's registers, so next to the main stream's kernels it starves them (measured: step 1.497 against 1.455 ms)
+        ws = L.workspace(int(L.lib.dd3d_conv128_bwd_weight_clouds_ws_bytes(M, G)), dev)
+        L.call("dd3d_conv128_bwd_weight_clouds", L.ptr(X), L.ptr(dY), L.ptr(nbr), ld, 27, M, L.ptr(seg), B, L.ptr(gro), G, L.ptr(dW),
+               L.ptr(err), L.ptr(ws), ws.numel(), L.stream())
+        return dW
+    ws = L.workspace(int(L.lib.dd3d_conv_bwd_weight_ws_bytes(M, G, 27, Cin, 128)), dev)
+    L.call("dd3d_conv_bwd_weight", L.ptr(X), Cin, L.ptr(dY), 128, L.ptr(nbr), ld, 27, M, L.ptr(gro), G, L.ptr(dW), L.ptr(ws), ws.numel(),
+           L.stream())
+    return dW
+
+
 class _Pass:
     """Forward + first-order backward of MEConvExp over ONE class-batched set of clouds -- the synthetic clouds first, then the real
     ones -- and the second-order backward over the synthetic prefix.
@@ -51,7 +68,7 @@ class _Pass:
     pass is the same kernels called on the first ``B_syn`` clouds with the prefix's row counts (``seg_off[B_syn]``, on the device)."""
 
     def __init__(self, net, coords, B, G, cloud_group, group_cloud_off, B_syn, N_syn, side, n_dev=None, static=False, pt_off=None, max_points=0,
-                 extent=None, side2=None):
+                 extent=None, side2=None, stash=None):
         """Phase 1 (no host sync): every coordinate map, enqueued on the current stream.
         ``static``: never read a size back -- every launch covers its bound and takes the true row count from the device
         (``n_dev`` = number of valid rows of ``coords``), so the pass can be captured into a HIP graph."""
@@ -64,10 +81,13 @@ class _Pass:
         self.extent = extent = tuple(net.dense_extent) if extent is None else tuple(extent)
         if pt_off is not None and 0 < max_points <= int(L.lib.dd3d_cloud_maps_max_points()):
             # clouds small enough for LDS: the whole pyramid (+ dense placement) in three launches
-            cm = CloudCoordinateManager(coords, pt_off, B, max_points, extent, cloud_group, G, group_cloud_off)
+            cm = CloudCoordinateManager(coords, pt_off, B, max_points, extent, cloud_group, G, group_cloud_off,
+                                        out=None if stash is None else {k: stash[k] for k in ("nbr1", "nbr2", "gro")})
         else:
+            if stash is not None:
+                raise ValueError("the deferred-loss mode needs the cloud-local map builder (clouds of at most 1024 points)")
             cm = CoordinateManager(coords, B, n_dev=n_dev)
-        self.cm = cm
+        self.cm, self.stash = cm, stash
         self.N = cm.N
         # every cloud has at most max_points voxel rows at any stride: small enough for the cloud-window kernel gradient?
         self.small_clouds = pt_off is not None and 0 < max_points <= int(L.lib.dd3d_conv128_bwd_weight_clouds_max_rows())
@@ -82,8 +102,12 @@ class _Pass:
             gro1, gro2 = seg1[gidx].contiguous(), seg2[gidx].contiguous()   # rows of every group at tensor strides 1 and 2
         self._pre = (k0, p0, k1, p1, seg1, seg2, gro1, gro2)
 
-    def run(self, feats, labels):
-        """Phase 2: (eager mode: ONE device->host read of the row counts, then) forward + first-order backward on the current stream."""
+    def run(self, feats, labels, defer=False):
+        """Phase 2: (eager mode: ONE device->host read of the row counts, then) forward + first-order backward on the current stream.
+        ``defer`` (needs a stash): the two kernel gradients of the convolutions, which feed nothing but the loss VALUE, are not launched here;
+        their operands are written into the stash, and FusedDistiller runs them next to the beginning of the following step."""
+        stash = self.stash
+        assert not defer or stash is not None
         net, dev, B, G, cm, dp = self.net, self.dev, self.B, self.G, self.cm, self.dp
         cloud_group, group_cloud_off = self.cloud_group, self.gco
         (k0, ld0), (p0, pl0), (k1, ld1), (p1, pl1), seg1, seg2, gro1, gro2 = self._pre
@@ -122,12 +146,12 @@ class _Pass:
 
         # ---------------- forward ----------------
         feats = feats.detach().contiguous()
-        F0 = self.F0 = _empty((M0, 3), dev)
+        F0 = self.F0 = stash["F0"][:M0] if stash is not None else _empty((M0, 3), dev)
         L.call("dd3d_voxel_mean_fwd", L.ptr(feats), self.N, 3, L.ptr(cm.vox_off), L.ptr(cm.vox_pts), M0, c0, L.ptr(F0), st)
         Y0 = _empty((M0, 128), dev)
         L.call("dd3d_conv_fwd", L.ptr(F0), M0, 3, L.ptr(W0), 128, L.ptr(k0), ld0, 27, M0, c0, 0, L.ptr(Y0), st)
         xh0, is0 = self.xh0, self.is0 = _empty((M0, 128), dev), _empty((B, 128), dev)
-        P0, arg0 = self.P0, self.arg0 = _empty((M1, 128), dev), _empty((M1, 128), dev, _I32)
+        P0, arg0 = self.P0, self.arg0 = (stash["P0"][:M1] if stash is not None else _empty((M1, 128), dev)), _empty((M1, 128), dev, _I32)
         # instance norm + affine + ReLU + max-pool of a level in one launch per cloud (the pooled rows re-read their children from cache)
         L.call("dd3d_inorm_arp_fwd", L.ptr(Y0), L.ptr(seg1), B, 128, L.ptr(xh0), L.ptr(is0), L.ptr(w1), L.ptr(b1), L.ptr(p0), pl0, 8, L.ptr(seg2),
                L.ptr(P0), L.ptr(arg0), st)
@@ -175,13 +199,15 @@ class _Pass:
         # the ReLU-masked pooled gradients (ga) are kept for the synthetic clouds only: the second-order pass needs nothing else
         Ns = max(self.N_syn, 1)
         self.ga1, self.ga0 = _empty((Ns, 128), dev), _empty((Ns, 128), dev)
-        gY1, g_w5, g_b5 = self._arp_inorm_bwd(gP1, arg1, cm.parent(4), xh1, is1, w5, b5, seg2, M1, B, G, self.ga1, self.B_syn, True)
+        gY1, g_w5, g_b5 = self._arp_inorm_bwd(gP1, arg1, cm.parent(4), xh1, is1, w5, b5, seg2, M1, B, G, self.ga1, self.B_syn, True,
+                                              dY_out=None if stash is None else stash["gY1"][:M1], gb_out=None if stash is None else stash["g_b5"])
         # Two launches want the matrix cores here: the input gradient of the 128-channel convolution (main stream, everything else waits
         # for it) and its kernel gradient (side stream, only the loss value waits for it).  Side by side they share the pipe and BOTH take
         # ~400 us; with the kernel gradient held back until the input gradient is done (DD3D_BWW_AFTER, default) the main stream gets the
         # pipe for ~200 us and the kernel gradient then overlaps the bandwidth-bound norm / pool backward and the second-order pass.
         after = os.environ.get("DD3D_BWW_AFTER", "1") != "0"
-        if not after:
+        g_W1 = g_W0 = None
+        if not after and not defer:
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 g_W1 = self._bww(P0, 128, gY1, k1, ld1, M1, gro2, seg2)
@@ -191,32 +217,36 @@ class _Pass:
                    L.ptr(gP0), st)
         else:
             L.call("dd3d_conv_bwd_data", L.ptr(gY1), M1, c1, 128, L.ptr(W1t), 128, L.ptr(k1), ld1, 27, L.ptr(gP0), st)
-        if after:
+        if after and not defer:
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 g_W1 = self._bww(P0, 128, gY1, k1, ld1, M1, gro2, seg2)
-        gY0, g_w1, g_b1 = self._arp_inorm_bwd(gP0, arg0, cm.parent(2), xh0, is0, w1, b1, seg1, M0, B, G, self.ga0, self.B_syn, True)
+        gY0, g_w1, g_b1 = self._arp_inorm_bwd(gP0, arg0, cm.parent(2), xh0, is0, w1, b1, seg1, M0, B, G, self.ga0, self.B_syn, True,
+                                              dY_out=None if stash is None else stash["gY0"][:M0], gb_out=None if stash is None else stash["g_b1"])
         # The first layer's kernel gradient feeds nothing but the loss VALUE either: it runs on a stream of its own next to the 128-channel
         # one (bandwidth-bound next to matrix-bound), and the main stream goes on to the matching loss of the differentiable entries and
         # the second-order pass (the caller joins the streams: FusedDistiller._compute)
         side2 = self.side2
-        side2.wait_stream(main)
-        with torch.cuda.stream(side2):
-            g_W0 = self._bww(F0, 3, gY0, k0, ld0, M0, gro1)
+        if not defer:
+            side2.wait_stream(main)
+            with torch.cuda.stream(side2):
+                g_W0 = self._bww(F0, 3, gY0, k0, ld0, M0, gro1)
         if not self.static:
             for t in (g_cb, g_cw, g_W1, g_W0):   # allocated on the side stream, consumed on the main one
-                t.record_stream(main)
+                if t is not None:
+                    t.record_stream(main)
         # order of network.parameters()
         self.gw = [g_W0, g_w1, g_b1, g_W1, g_w5, g_b5, g_cw, g_cb]
         return self
 
-    def _arp_inorm_bwd(self, g_pool, arg, parent, xhat, inv_std, w, b, seg, M_in, B, G, ga_out, ga_clouds, want_gw, ga_prev=None, gw_extra=None):
+    def _arp_inorm_bwd(self, g_pool, arg, parent, xhat, inv_std, w, b, seg, M_in, B, G, ga_out, ga_clouds, want_gw, ga_prev=None, gw_extra=None,
+                       dY_out=None, gb_out=None):
         """Backward of max-pool -> ReLU -> affine -> instance norm in one pass per cloud, over the first B clouds:
         (dY, d weight [G,128], d bias [G,128]); ``ga_out`` receives the masked pooled gradient of the first ``ga_clouds`` clouds."""
         dev = self.dev
-        dY = _empty((M_in, 128), dev)
+        dY = dY_out if dY_out is not None else _empty((M_in, 128), dev)
         gw_w = _empty((G, 128), dev) if want_gw else None
-        gw_b = _empty((G, 128), dev) if want_gw else None
+        gw_b = (gb_out if gb_out is not None else _empty((G, 128), dev)) if want_gw else None
         ws = L.workspace(int(L.lib.dd3d_arp_inorm_bwd_ws_bytes(B)), dev)
         L.call("dd3d_arp_inorm_bwd", L.ptr(g_pool), L.ptr(arg), L.ptr(parent), L.ptr(xhat), L.ptr(inv_std), L.ptr(w), L.ptr(b), 128, L.ptr(seg), B,
                L.ptr(self.cloud_group), L.ptr(self.gco), G, L.ptr(dY), L.ptr(ga_out), int(ga_clouds), L.ptr(ga_prev), L.ptr(gw_extra), L.ptr(gw_w),
@@ -224,20 +254,9 @@ class _Pass:
         return dY, gw_w, gw_b
 
     def _bww(self, X, Cin, dY, nbr, ld, M, gro, seg=None):
-        G = self.G
-        dW = _empty((G, 27, Cin, 128), self.dev)
-        if Cin == 128 and seg is not None and self.small_clouds and os.environ.get("DD3D_BWW_CLOUDS", "0") != "0":
-            # small clouds: whole-cloud windows of both operands in LDS (conv_bww.hip).  Off by default: alone it takes what the row-chunk kernel
-            # and its slab sum take (243 + 10 us against 223 + 30 us at cfg2, with a quarter of the memory traffic), but its workgroups fill a
-            # CU's registers, so next to the main stream's kernels it starves them (measured: step 1.497 against 1.455 ms)
-            ws = L.workspace(int(L.lib.dd3d_conv128_bwd_weight_clouds_ws_bytes(M, G)), self.dev)
-            L.call("dd3d_conv128_bwd_weight_clouds", L.ptr(X), L.ptr(dY), L.ptr(nbr), ld, 27, M, L.ptr(seg), self.B, L.ptr(gro), G, L.ptr(dW),
-                   L.ptr(self.cm.err), L.ptr(ws), ws.numel(), L.stream())
-            return dW
-        ws = L.workspace(int(L.lib.dd3d_conv_bwd_weight_ws_bytes(M, G, 27, Cin, 128)), self.dev)
-        L.call("dd3d_conv_bwd_weight", L.ptr(X), Cin, L.ptr(dY), 128, L.ptr(nbr), ld, 27, M, L.ptr(gro), G, L.ptr(dW), L.ptr(ws), ws.numel(),
-               L.stream())
-        return dW
+        return conv_kernel_gradient(X, Cin, dY, nbr, ld, M, gro, self.G, self.dev, seg if self.small_clouds else None, self.B, self.cm.err)
+
+
 
     # ---------------- second-order backward into the synthetic points: the same kernels on the synthetic prefix ----------------
     def backward_to_points(self, G_w1, G_w5, G_cw, G_cb, per):
@@ -276,7 +295,8 @@ class _Pass:
         return dfeats
 
 
-def grouped_match_loss(gw_syn: List[torch.Tensor], gw_real: List[torch.Tensor], dis_metric: str, G: int, need_grad, pyt: bool = False):
+def grouped_match_loss(gw_syn: List[torch.Tensor], gw_real: List[torch.Tensor], dis_metric: str, G: int, need_grad, pyt: bool = False,
+                       loss_out: Optional[torch.Tensor] = None):
     """distillation_loss.match_loss for G classes at once: tensors are [G, *param_shape]; returns (loss[G], grads list).  With no gradient
     requested only the forward launches run."""
     if dis_metric not in _METRICS:
@@ -294,7 +314,7 @@ def grouped_match_loss(gw_syn: List[torch.Tensor], gw_real: List[torch.Tensor], 
         segs[i].dsyn = dsyn[i].data_ptr() if dsyn[i] is not None else None
         segs[i].rows, segs[i].cols, segs[i].colmajor = layout[i]
     stats = _empty((int(L.lib.dd3d_match_loss_stats_floats(segs, n, G)),), dev)
-    loss = _empty((G,), dev)
+    loss = loss_out if loss_out is not None else _empty((G,), dev)
     ws = L.workspace(int(L.lib.dd3d_match_loss_ws_bytes(segs, n, G)), dev)
     L.call("dd3d_match_loss_fwd", segs, n, G, metric, L.ptr(loss), L.ptr(stats), L.ptr(ws), ws.numel(), L.stream())
     if any(need_grad):
@@ -394,7 +414,7 @@ class FusedDistiller:
 
     def __init__(self, images_all, indices_class, network, ipc, num_classes=10, num_points=250, batch_size=256, dist_opt="modmse",
                  dist_lr=0.1, device=None, seed=0, image_syn=None, classes=None, momentum=0.5, graph=True, real_clouds=None,
-                 quantization_size=1.0, clamp_range=(0.0, 27.0), zero_first_axis=True):
+                 quantization_size=1.0, clamp_range=(0.0, 27.0), zero_first_axis=True, defer_loss=False):
         """``real_clouds`` (optional, instead of ``images_all``): the real data as point clouds -- a float tensor [n, P, 3] or a list of
         [n_i, 3] tensors; coordinates = features = the points (what Mnist2Dreal does with pixels), coordinates divided by
         ``quantization_size`` (create_input_batch).  ``clamp_range`` / ``zero_first_axis``: the per-iteration clamp of the synthetic
@@ -434,12 +454,22 @@ class FusedDistiller:
         self.syn_batch_col = torch.arange(G * ipc, device=dev, dtype=_F32).repeat_interleave(num_points)[:, None]
         self.last = {}
         self.stream_side = torch.cuda.Stream(dev)   # parameter-gradient kernels that only the loss consumes
-        self.stream_side2 = torch.cuda.Stream(dev)  # the first layer's kernel gradient, next to the 128-channel one
+        # the first layer's kernel gradient, next to the 128-channel one.  Deferred-loss mode: all of the previous step's loss-value work
+        # (a capture with a fourth stream crashed hipStreamEndCapture on ROCm 7.2, so it shares this one)
+        self.stream_side2 = torch.cuda.Stream(dev)
+        self.stream_defer = self.stream_side2
         # eager mode: next step's real batch is sampled on its own stream while this step's kernels run
         self.stream_data, self._prefetched = torch.cuda.Stream(dev), None
         self.use_graph = bool(graph) and G > 0
+        # Deferred loss value (graph mode, layer-additive metrics): the two kernel gradients of the convolutions and the loss terms over them
+        # feed nothing but the VALUE of the matching loss -- not the update of the synthetic points.  With ``defer_loss`` a step leaves
+        # their operands in a stash (two sets, alternating) and the NEXT step's graph computes them on side streams next to its own
+        # map building and first layer, where the matrix cores are idle.  ``outer_step`` then returns the complete loss of the PREVIOUS
+        # step (zero on the first one); ``flush()`` completes and returns the last step's.  Same kernels, same bits, one step later.
+        self.defer = bool(defer_loss) and self.use_graph and dist_opt in ("ours", "modmse", "mse")
+        self._stash, self._pending, self._graphs = None, None, [None, None]
         self._graph = self._static = None
-        self._graph_stamp, self._needs_eager = None, False
+        self._graph_stamp, self._needs_eager, self._last_loss = None, False, None
         self._scope = "graph%x" % id(self)
 
     def _param_stamp(self):
@@ -450,7 +480,7 @@ class FusedDistiller:
         """Drop the captured graph and the cached weight layouts (transposed 128-channel kernel, site-major classifier weight).  Called
         automatically when a parameter's address or version counter changed since the capture; call it yourself after editing weights
         through ``.data`` (which bumps no version counter).  The next step runs eagerly and rebuilds the layouts, the one after re-captures."""
-        self._graph = None
+        self._graph, self._graphs = None, [None, None]
         self._needs_eager = True
         for p in self.network.parameters():
             for attr in ("_dd3d_csm", "_dd3d_wt", "_dd3d_sm"):
@@ -593,6 +623,12 @@ class FusedDistiller:
         st.cloud_group = torch.cat([self.syn_group, rg + G])
         st.gco = torch.cat([self.syn_gco, rgco + Bs])
         st.max_per = int(max(sizes))
+        if self.defer:
+            bt, G2 = st.bound_total, 2 * G
+            self._stash = [{"F0": _empty((bt, 3), dev), "P0": _empty((bt, 128), dev), "gY1": _empty((bt, 128), dev), "gY0": _empty((bt, 128), dev),
+                            "nbr1": _empty((27, bt), dev, _I32), "nbr2": _empty((27, bt), dev, _I32), "gro": _empty((3, G2 + 1), dev, _I32),
+                            "g_b1": _empty((G2, 128), dev), "g_b5": _empty((G2, 128), dev), "loss_a": torch.zeros(G, device=dev),
+                            "loss": torch.zeros(G, device=dev), "ld": bt, "parity": i} for i in range(2)]
         st.pin = [torch.empty(max(st.B, 1), dtype=_I32).pin_memory() for _ in range(4)]
         st.pin_ev = [torch.cuda.Event() for _ in range(4)]
         st.pin_i = 0
@@ -624,9 +660,39 @@ class FusedDistiller:
                 "group_cloud_off": torch.cat([self.syn_gco, rb["group_cloud_off"][1:] + Bs]),
                 "pt_off": torch.cat([self.syn_pt_off, pt[1:] + Ns]), "n_dev": None, "extent": rb.get("extent")}
 
-    def _compute(self, mb, static):
+    def _run_deferred(self, stash):
+        """The loss-value-only work a deferred step left behind: both convolutions' kernel gradients over the stashed operands (the
+        first layer's on the second side stream) and the matching-loss terms over them and the two instance-norm biases;
+        stash["loss"] = the step's complete per-class loss.  Enqueued on the side stream(s); the caller joins."""
+        G, dev, bt = self.G, self.device, stash["ld"]
+        side, side2 = self.stream_defer, self.stream_side2   # not stream_side: this step's classifier gradients must not queue behind them
+        if side2 is not side:
+            side2.wait_stream(side)
+        with torch.cuda.stream(side2):
+            g_W0 = conv_kernel_gradient(stash["F0"], 3, stash["gY0"], stash["nbr1"], bt, bt, stash["gro"][0], 2 * G, dev)
+        with torch.cuda.stream(side):
+            g_W1 = conv_kernel_gradient(stash["P0"], 128, stash["gY1"], stash["nbr2"], bt, bt, stash["gro"][1], 2 * G, dev)
+            if side2 is not side:
+                side.wait_stream(side2)
+            gw = [g_W0, stash["g_b1"], g_W1, stash["g_b5"]]
+            loss_b, _ = grouped_match_loss([t[:G] for t in gw], [t[G:] for t in gw], self.dist_opt, G, [False] * 4)
+            torch.add(stash["loss_a"], loss_b, out=stash["loss"])
+
+    def flush(self):
+        """Deferred-loss mode: complete the last step's loss value now (the same launches the next step's graph would make) and return it
+        (0-d device tensor).  Without a pending step, or outside the deferred mode: the last returned loss."""
+        if self._pending is None:
+            return self._last_loss
+        main = torch.cuda.current_stream(self.device)
+        self.stream_defer.wait_stream(main)
+        with L.ws_scope(self._scope + "flush"):
+            self._run_deferred(self._pending)
+        main.wait_stream(self.stream_defer)
+        return self._pending["loss"].sum()
+
+    def _compute(self, mb, static, stash=None):
         """Everything after the merged batch ``mb`` exists: one forward / first-order backward over synthetic + real clouds, the matching
-        loss, the second-order backward into the synthetic points, the SGD update."""
+        loss, the second-order backward into the synthetic points, the SGD update.  ``stash``: deferred-loss mode (see __init__)."""
         dev, G, ipc, npts = self.device, self.G, self.ipc, self.num_points
         # cached layouts of the frozen weights are (re)built here if a weight changed
         net = self.network
@@ -634,9 +700,9 @@ class FusedDistiller:
         compact_site_major(net.classifier.weight, 128, net.dense_extent, extent)
         transposed_kernel(net.features[4].kernel)
         p = _Pass(net, mb["coordinates"], int(mb["num_clouds"]), 2 * G, mb["cloud_group"], mb["group_cloud_off"], G * ipc, G * ipc * npts,
-                  self.stream_side, mb.get("n_dev"), static, mb.get("pt_off"), npts, extent, self.stream_side2)
-        p.run(mb["features"], mb["labels"])
-        gw_syn, gw_real = [t[:G] for t in p.gw], [t[G:] for t in p.gw]
+                  self.stream_side, mb.get("n_dev"), static, mb.get("pt_off"), npts, extent, self.stream_side2, stash)
+        p.run(mb["features"], mb["labels"], defer=stash is not None)
+        gw_syn, gw_real = [None if t is None else t[:G] for t in p.gw], [None if t is None else t[G:] for t in p.gw]
         # Only these entries of gw_syn depend on the synthetic points: IN weights, classifier weight and bias.  For the
         # layer-additive metrics the loss is split accordingly: the part over these four entries (with its gradient) runs on the main stream
         # as soon as they exist, and the second-order pass follows at once; the VALUE of the other four (both kernel gradients, both IN
@@ -644,7 +710,13 @@ class FusedDistiller:
         # layers together and keeps the joint launch.
         main, side = torch.cuda.current_stream(dev), self.stream_side
         diff, const = [1, 4, 6, 7], [0, 2, 3, 5]
-        if self.dist_opt in ("ours", "modmse", "mse") and os.environ.get("DD3D_LOSS_SPLIT", "1") != "0":
+        if stash is not None:
+            main.wait_event(p.ev_cls)
+            loss_a, d4 = grouped_match_loss([gw_syn[i] for i in diff], [gw_real[i] for i in diff], self.dist_opt, G, [True] * 4, loss_out=stash["loss_a"])
+            dfeats = p.backward_to_points(d4[0], d4[1], d4[2], d4[3], ipc)
+            main.wait_stream(side)   # the classifier gradients' stream (and whatever else the caller put there) joins before the update
+            loss_g = loss_a
+        elif self.dist_opt in ("ours", "modmse", "mse") and os.environ.get("DD3D_LOSS_SPLIT", "1") != "0":
             main.wait_event(p.ev_cls)
             loss_a, d4 = grouped_match_loss([gw_syn[i] for i in diff], [gw_real[i] for i in diff], self.dist_opt, G, [True] * 4)
             side.wait_stream(p.side2)
@@ -679,9 +751,11 @@ class FusedDistiller:
                    self.momentum, 0, 0, 0.0, 27.0, L.stream())
         return loss_g.sum()
 
-    def _static_body(self):
-        """clamp + on-device batch assembly + the step, all on fixed addresses with device-side sizes (what the graph captures)."""
+    def _static_body(self, parity=0):
+        """clamp + on-device batch assembly + the step, all on fixed addresses with device-side sizes (what the graph captures).
+        Deferred-loss mode: the previous step's pending loss-value work first, on the side streams, next to this step's own kernels."""
         st = self._static
+        stash = self._stash[parity] if self.defer else None
         Bs, Ns = self.G * self.ipc, self.G * self.ipc * self.num_points
         # clamp + the owned synthetic clouds into the head of the merged batch (coordinates = xyz / quantization_size, features = xyz:
         # the same tensor twice, Mnist2D.py:84-92), one launch
@@ -689,12 +763,25 @@ class FusedDistiller:
         L.call("dd3d_syn_head", L.ptr(self.image_syn), self.image_syn.shape[0], self.num_points, L.ptr(self.dest_cloud), int(cr is not None),
                float(cr[0]) if cr else 0.0, float(cr[1]) if cr else 0.0, int(self.zero_first_axis), self.quant, L.ptr(st.coords), L.ptr(st.feats),
                L.stream())
+        # (forked behind the first kernel of the step: a fork from a capture stream that has no node yet crashed hipStreamEndCapture)
+        if self.defer and self._pending is not None:
+            self.stream_defer.wait_stream(torch.cuda.current_stream(self.device))
+            with L.ws_scope(self._scope + "d%d" % parity):
+                self._run_deferred(self._pending)
         L.call("dd3d_gather_clouds", L.ptr(st.pool_xyz), L.ptr(st.pool_off), st.n_pool, L.ptr(st.ids), st.B, self.num_points, st.bound_total,
                Bs, Ns, self.quant, L.ptr(st.coords), L.ptr(st.feats), L.ptr(st.pt_off), L.ptr(st.n), L.ptr(st.err), L.stream())
         mb = {"coordinates": st.coords, "features": st.feats, "labels": st.labels, "num_clouds": Bs + st.B, "cloud_group": st.cloud_group,
               "group_cloud_off": st.gco, "n_dev": st.n, "pt_off": st.pt_off}
-        with L.ws_scope(self._scope):
-            return self._compute(mb, True)
+        with L.ws_scope(self._scope + ("p%d" % parity if self.defer else "")):
+            out = self._compute(mb, True, stash)
+        if self.defer:
+            main = torch.cuda.current_stream(self.device)
+            main.wait_stream(self.stream_defer)   # (also what lets a capture end: every forked stream rejoins)
+            if self.stream_side2 is not self.stream_defer:
+                main.wait_stream(self.stream_side2)
+            prev, self._pending = self._pending, stash
+            return prev["loss"].sum() if prev is not None else torch.zeros((), device=self.device)
+        return out
 
     def row_counts(self):
         """((M0, M1, M2),) of the last step's merged batch (one device->host read in graph mode)."""
@@ -717,21 +804,24 @@ class FusedDistiller:
             self._upload_ids()
             if self._graph is not None and self._param_stamp() != self._graph_stamp:
                 self.invalidate()   # a weight changed (load_state_dict, optimizer step): the captured graph reads stale cached layouts
+            parity = self.steps_done % 2 if self.defer else 0
             if force_eager or self.steps_done == 0 or self._needs_eager:
                 # the first step runs eagerly: it sizes the workspaces and builds the cached weight layouts the graph will reuse
-                loss = self._static_body()
+                loss = self._static_body(parity)
                 self._needs_eager = False
             else:
-                if self._graph is None:
-                    self._graph = torch.cuda.CUDAGraph()
+                if self._graphs[parity] is None:
+                    g = torch.cuda.CUDAGraph()
                     # thread_local: only this thread's calls are checked during capture (an RCCL watchdog thread polling its events
                     # must not invalidate it)
-                    with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
-                        self._graph_loss = self._static_body()
-                    self._graph_last = self.last
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        gl = self._static_body(parity)
+                    # deferred mode: the graph of parity p runs the pending work of the step before it (stash 1 - p) and leaves its own in stash p
+                    self._graphs[parity] = (g, gl, self.last, self._pending)
                     self._graph_stamp = self._param_stamp()
+                self._graph, loss, self.last, self._pending = self._graphs[parity]
                 self._graph.replay()
-                loss, self.last = self._graph_loss, self._graph_last
+            self._last_loss = loss
             self.steps_done += 1
             return loss
         self.clamp()

@@ -205,7 +205,10 @@ class CloudCoordinateManager(CoordinateManager):
     bit-identical to what ``CoordinateManager`` builds call by call; other strides / kernel sizes are not available here."""
 
     def __init__(self, coords: torch.Tensor, pt_off: torch.Tensor, num_clouds: int, max_points: int, dense_extent=None,
-                 cloud_group: Optional[torch.Tensor] = None, num_groups: int = 1, group_cloud_off: Optional[torch.Tensor] = None):
+                 cloud_group: Optional[torch.Tensor] = None, num_groups: int = 1, group_cloud_off: Optional[torch.Tensor] = None,
+                 out: Optional[dict] = None):
+        """``out`` (optional): caller-owned buffers for the outputs that outlive the step in the deferred-loss mode of the fused step --
+        ``nbr1`` / ``nbr2`` int32 [27, >= N] and ``gro`` int32 [3, num_groups + 1]; their leading dimension is the table stride."""
         if coords.dim() != 2 or coords.shape[1] != 4:
             raise ValueError("coordinates must be [N,4] = (batch, c1, c2, c3)")
         coords = coords.detach().to(torch.float32).contiguous()
@@ -224,7 +227,12 @@ class CloudCoordinateManager(CoordinateManager):
         C = [i32(bound, 4) for _ in range(3)]
         inv1, uidx1, par2, uidx2, par4, uidx4 = (i32(bound) for _ in range(6))
         self.vox_off, self.vox_pts = i32(bound + 1), i32(bound)
-        nbr1, nbr2, kid2, kid4 = i32(27, bound), i32(27, bound), i32(8, bound), i32(8, bound)
+        out = out or {}
+        nbr1 = out["nbr1"] if "nbr1" in out else i32(27, bound)
+        nbr2 = out["nbr2"] if "nbr2" in out else i32(27, bound)
+        if nbr1.shape[1] != bound or nbr2.shape[1] != bound or not (nbr1.is_contiguous() and nbr2.is_contiguous()):
+            raise ValueError("caller-owned neighbour tables must be contiguous [27, N]")
+        kid2, kid4 = i32(8, bound), i32(8, bound)
         seg = i32(3, B + 1)
         self.dense_tables = None
         E, gmin, site, vox_at = (0, 0, 0), None, None, None
@@ -232,7 +240,7 @@ class CloudCoordinateManager(CoordinateManager):
             E = tuple(int(e) for e in dense_extent)
             gmin, site, vox_at = i32(num_groups, 3), i32(bound), i32(E[0] * E[1] * E[2], max(B, 1))
             self.dense_tables = (E, cloud_group, gmin, site, vox_at)
-        self.group_row_off = i32(3, num_groups + 1) if group_cloud_off is not None else None   # rows of every group at strides 1, 2, 4
+        self.group_row_off = (out["gro"] if "gro" in out else i32(3, num_groups + 1)) if group_cloud_off is not None else None   # rows of every group at strides 1, 2, 4
         ws = L.workspace(int(L.lib.dd3d_cloud_maps_ws_bytes(B)), dev)
         L.call("dd3d_cloud_maps", L.ptr(coords), L.ptr(pt_off), B, int(max_points), self.N, L.ptr(cloud_group), int(num_groups), E[0], E[1], E[2],
                L.ptr(self.counts), L.ptr(seg), L.ptr(C[0]), L.ptr(C[1]), L.ptr(C[2]), L.ptr(inv1), L.ptr(uidx1), L.ptr(self.vox_off),

@@ -382,3 +382,28 @@ def test_graph_follows_a_weight_change():
         assert lg == le, f"step {step} after the weight change: graph {lg} vs eager {le}"
         assert torch.equal(fg.image_syn, fe.image_syn)
     assert fg._graph is not None   # re-captured
+
+
+@pytest.mark.parametrize("metric", ["modmse", "ours"])
+def test_deferred_loss_mode_is_the_same_step_one_step_later(metric):
+    """defer_loss=True: the loss-value-only work of a step (both convolutions' kernel gradients and the loss terms over them) runs inside
+    the NEXT step's graph.  The synthetic points must move exactly as in the eager step, flush() must give the step's loss bit for bit,
+    and the value outer_step returns must be the previous step's complete loss."""
+    from dd3d_amd.fused_step import FusedDistiller
+    from dd3d_amd.synthetic import mnist3d_like
+    images, _, idx = mnist3d_like(4, 40, seed=3)
+    syn = init_synthetic(4, 3, 250, seed=1)
+    kw = dict(ipc=3, num_classes=4, batch_size=24, dist_opt=metric, device=DEV, seed=11, image_syn=syn)
+    fd = FusedDistiller(images, idx, _net(), graph=True, defer_loss=True, **kw)
+    fd2 = FusedDistiller(images, idx, _net(), graph=True, defer_loss=True, **kw)   # never flushed between steps
+    fe = FusedDistiller(images, idx, _net(), graph=False, **kw)
+    prev = 0.0
+    for step in range(6):
+        ret, ret2, le = fd.outer_step().item(), fd2.outer_step().item(), fe.outer_step().item()
+        assert ret == prev and ret2 == prev, f"step {step}: returned {ret} / {ret2}, previous step's loss {prev}"
+        assert torch.equal(fd.image_syn, fe.image_syn) and torch.equal(fd2.image_syn, fe.image_syn)
+        assert fd.flush().item() == le, f"step {step}: flushed loss differs from the eager step's"
+        prev = le
+    assert fd2.flush().item() == prev
+    fd.check()
+    assert all(g is not None for g in fd._graphs)
