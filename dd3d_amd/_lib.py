@@ -8,7 +8,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdd3d_hip.so")
+# DD3D_LIB: another build of the same library (tools/ab.sh comparison builds, the `make prof` build) without touching the product .so
+LIB_PATH = os.environ.get("DD3D_LIB") or os.path.join(_HERE, "libdd3d_hip.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -51,8 +52,8 @@ _SIGS = {
     "dd3d_conv_schedule_tile_rows": (I32, [I64]),
     "dd3d_conv_schedule_blocks": (I64, [I64]),
     "dd3d_conv_schedule_ws_bytes": (I64, [I64]),
-    "dd3d_conv_schedule": (I32, [P, I64, I32, I64, P, P, P, P, I64, P]),
-    "dd3d_conv128_ordered": (I32, [P, I64, P, P, I64, I32, I64, P, I32, P, P, P, P]),
+    "dd3d_conv_schedule": (I32, [P, I64, I32, I64, P, P, P, P, P, P, I64, P]),
+    "dd3d_conv128_ordered": (I32, [P, I64, P, P, I64, I32, I64, P, I32, P, P, P, P, P, P]),
     "dd3d_conv128_split_ws_bytes": (I64, [I64]),
     "dd3d_conv128_split": (I32, [P, I64, P, P, I64, I32, I64, P, I32, P, P, I64, P]),
     "dd3d_conv_bwd_data": (I32, [P, I64, P, I32, P, I32, P, I64, I32, P, P]),

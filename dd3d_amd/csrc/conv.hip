@@ -10,6 +10,7 @@
 // Cin == 3 (first layer) is a bandwidth kernel on the VALU (a 3-wide contraction has nothing for MFMA to do).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -221,10 +222,22 @@ __global__ __launch_bounds__(256) void k_split_sum(const f32x4* __restrict__ par
 // the 16 KB weight chunk of a step is shared, double-buffered in LDS: ONE barrier per step, and the loads of step s+1 (A into the
 // other register set, W into staging registers) are in flight under the 64 MFMAs of step s.  The k-index assignment and the
 // order of the accumulation are those of k_conv128, so the two kernels give bit-identical results.
+#ifndef DD3D_EXP
+#define DD3D_EXP 0
+#endif
+#ifdef DD3D_CONV_PROF  // `make prof`: wave 0..3 of the first 1024 workgroups leave timestamps (100 MHz wall clock) and their placement
+__device__ long long g_prof[1024 * 4 * 8];
+#define PROF_T(x) const long long x = wall_clock64()
+#define PROF_ADD(acc, a, b) acc += (b) - (a)
+#else
+#define PROF_T(x)
+#define PROF_ADD(acc, a, b)
+#endif
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_conv128_rows(const float* __restrict__ X, const float* __restrict__ W, const int* __restrict__ nbr, int64_t ld,
                                                           int K, int M_bound, const int* __restrict__ m_dev, int mirror, float* __restrict__ Y, int xcd_remap,
-                                                          const int* __restrict__ perm, const int* __restrict__ tile_map) {
+                                                          const int* __restrict__ perm, const int* __restrict__ tile_map,
+                                                          const int* __restrict__ nbr_sorted, const unsigned* __restrict__ tile_mask) {
     constexpr int TM = NW * 32, NTH = NW * 64, BPT = 1024 / NTH;
     __shared__ f32x4 Bs4[2][32 * 32];
     __shared__ int s_nbr[27 * TM];
@@ -242,30 +255,53 @@ __global__ __launch_bounds__(NW * 64) void k_conv128_rows(const float* __restric
     const int64_t row0 = (int64_t)tile * TM;
     if (tile >= ntile || (!tile_map && xcd_remap && (int)(blockIdx.x >> 3) >= per_xcd)) return;
 
-    if (tid == 0) s_kmask = 0;
-    if (tid < TM) {
-        const int64_t slot = row0 + tid;
-        s_row[tid] = slot < M_out ? (perm ? perm[slot] : (int)slot) : M_out;  // slots past the end (and rows a partial window maps past it) are dead
+    PROF_T(pt0);
+    // Neighbour table of the tile: thread t takes tile slot t % TM and every second offset, all of its table reads in flight together.
+    // A scheduled launch brings the table in pattern order (nbr_sorted: the slots of a tile are consecutive, coalesced reads) and the
+    // offsets present in the tile (tile_mask: the others are not read at all); without them the columns are gathered through perm --
+    // scattered 4-byte reads that cost a tile of the sorted order ~12 us before its first MFMA.
+    constexpr int KPT = (27 + 1) / 2;
+    static_assert(NTH == 2 * TM, "two threads per tile slot");
+    const int slot_r = tid & (TM - 1), k_first = tid / TM;
+    const int64_t slot = row0 + slot_r;
+    const int my_row = slot < M_out ? (perm ? perm[slot] : (int)slot) : M_out;  // slots past the end are dead
+    unsigned tmask = tile_mask ? tile_mask[tile] : 0x7fffffffu;
+    const bool in_order = nbr_sorted && !(tmask >> 31);
+    const int* nbr_col = in_order ? nbr_sorted + min(slot, (int64_t)M_out - 1) : nbr + min(my_row, M_out - 1);  // clamped, no branch on the row
+    int v_nbr[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const int kk = min(k_first + 2 * j, K - 1), ks = mirror ? K - 1 - kk : kk;  // table row ks serves offset kk of a mirrored launch
+        v_nbr[j] = -1;
+        if ((tmask >> ks) & 1u) v_nbr[j] = nbr_col[(int64_t)ks * ld];  // (uniform per wave: k_first is)
     }
+#pragma unroll
+    for (int j = 0; j < KPT; ++j)
+        if (k_first + 2 * j >= K || my_row >= M_out) v_nbr[j] = -1;
+    if (tid == 0) s_kmask = 0;
+    if (tid < TM) s_row[tid] = my_row;
     __syncthreads();
     unsigned mymask = 0;
-    for (int idx = tid; idx < K * TM; idx += NTH) {
-        int k = idx / TM, r = idx - k * TM;
-        const int row = s_row[r];
-        int ks = mirror ? K - 1 - k : k;
-        int v = row < M_out ? nbr[(int64_t)ks * ld + row] : -1;
-        s_nbr[idx] = v;
-        if (v >= 0) mymask |= 1u << k;
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const int kk = k_first + 2 * j;
+        if (kk < K) s_nbr[kk * TM + slot_r] = v_nbr[j];
+        if (v_nbr[j] >= 0) mymask |= 1u << kk;
     }
     if (mymask) atomicOr(&s_kmask, mymask);
     __syncthreads();
     const unsigned kmask = s_kmask;
+    // (No per-wave skip of an offset none of the wave's 32 rows has: in pattern order a tile's union is 1.03x the algorithmic work, and the
+    // branch around the MFMA block made the compiler shuttle the accumulators between register files every step.)
+#ifdef DD3D_CONV_PROF
     unsigned wmask = 0;  // offsets with a neighbour for one of THIS wave's 32 rows
     for (unsigned rest = kmask; rest; rest &= rest - 1) {
         const int k = __builtin_ctz(rest);
         if (__ballot(s_nbr[k * TM + wid * 32 + i32] >= 0)) wmask |= 1u << k;
     }
+#endif
 
+    PROF_T(pt1);
     f32x16 acc[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n)
@@ -273,61 +309,97 @@ __global__ __launch_bounds__(NW * 64) void k_conv128_rows(const float* __restric
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
     const f32x4* X4 = (const f32x4*)X;
     const f32x4* W4 = (const f32x4*)W;
+#ifdef DD3D_CONV_PROF
+    long long sg0 = 0, sg1 = 0, sg2 = 0, sg3 = 0;
+#endif
 
-    f32x4 raA[4], raB[4], rb[BPT];
-    auto load_a = [&](f32x4(&ra)[4], int nb, int kc) {  // clamped address: no branch, the four loads are issued together
-        const f32x4* p = X4 + (int64_t)max(nb, 0) * 32 + kc * 8 + h * 4;
+    static_assert(BPT <= 4, "eight load slots per step: four gathered A quads, up to four weight quads");
+    f32x4 cur[4], nxt[4], rb[BPT];
+    int k = kmask ? __builtin_ctz(kmask) : -1, kc = 0, nb = -1, buf = 0;
+    if (k >= 0) {
+        nb = s_nbr[k * TM + wid * 32 + i32];
+        const f32x4* pa = X4 + (int64_t)max(nb, 0) * 32 + h * 4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ra[j] = p[j];
-    };
-    auto load_b = [&](int k, int kc) {
+        for (int j = 0; j < 4; ++j) cur[j] = pa[j];
 #pragma unroll
-        for (int j = 0; j < BPT; ++j) rb[j] = W4[((int64_t)k * 128 + kc * 32) * 32 + j * NTH + tid];
-    };
-    auto store_b = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < BPT; ++j) Bs4[buf][j * NTH + tid] = rb[j];
-    };
-    int k = kmask ? __builtin_ctz(kmask) : -1, kc = 0, nb = -1, nk = -1, nkc = 0, nbn = -1;
-    // one step: issue the loads of the next step, multiply the current one, publish the next weight chunk; returns false after the last step
-    auto step = [&](f32x4(&cur)[4], f32x4(&nxt)[4], const int buf) -> bool {
-        nk = k, nkc = kc + 1, nbn = nb;
+        for (int j = 0; j < BPT; ++j) Bs4[0][j * NTH + tid] = W4[(int64_t)k * 128 * 32 + j * NTH + tid];
+        __syncthreads();
+    }
+    // One step = 16 k-pairs x 4 column blocks = 64 MFMAs on the weight chunk in Bs4[buf].  A wave issues its MFMAs in order and the pipe
+    // takes one every 64 cycles, so whatever else the wave has to issue must sit BETWEEN them to cost nothing: the weight fragments of
+    // k-pairs s+2, s+3 are read from LDS while s, s+1 multiply, and the eight global loads of the NEXT step (four quads of the wave's
+    // gathered rows, clamped address and no branch, and its share of the next weight chunk) go out one per two k-pairs.
+    // Every step runs the same code, the last one included (it "prefetches" its own operands again and publishes them to nobody): with
+    // the loads and the store under two separate `next exists` tests the compiler's wait-count pass saw a path "loads issued, store
+    // skipped, loop again" and put waits for a step's own prefetch in front of its MFMAs.
+    while (k >= 0) {
+        PROF_T(q0);
+        // the step after (k, kc): the next 32-channel chunk, or the first chunk of the next offset present in the tile
+        int nk = k, nkc = kc + 1, nbn = nb;
         if (nkc == 4) {
             nkc = 0;
             const unsigned rest = k + 1 < 32 ? kmask >> (k + 1) : 0u;
             nk = rest ? k + 1 + __builtin_ctz(rest) : -1;
             if (nk >= 0) nbn = s_nbr[nk * TM + wid * 32 + i32];
         }
-        if (nk >= 0) {
-            load_a(nxt, nbn, nkc);
-            load_b(nk, nkc);
-        }
-        if ((wmask >> k) & 1u) {
+        const bool more = nk >= 0;
+        if (!more) nk = k, nkc = kc;
+#if DD3D_EXP == 3
+        const f32x4* pa = X4 + (int64_t)((nk * 977 + tile * 32 + i32) % M_out) * 32 + nkc * 8 + h * 4;
+#else
+        const f32x4* pa = X4 + (int64_t)max(nbn, 0) * 32 + nkc * 8 + h * 4;
+#endif
+        const f32x4* pw = W4 + ((int64_t)nk * 128 + nkc * 32) * 32 + tid;
+        PROF_T(q1);
+        {
             const bool valid = nb >= 0;
             const f32x4* Bp = &Bs4[buf][(h * 16) * 32 + i32];
+            f32x4 b0 = Bp[0], b1 = Bp[32];
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const f32x4 b = Bp[s * 32];
-                const float a = valid ? cur[s >> 2][s & 3] : 0.f;
+            for (int s = 0; s < 16; s += 2) {
+                f32x4 n0 = b0, n1 = b1;
+                if (s + 2 < 16) n0 = Bp[(s + 2) * 32], n1 = Bp[(s + 3) * 32];
+#if DD3D_EXP != 1
+                if (s == 0) {
 #pragma unroll
-                for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[n], acc[n], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) nxt[j] = pa[j];
+                }
+#else
+                if (s == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) nxt[j] = cur[j];
+                }
+#endif
+                if (DD3D_EXP != 2 && s < 4) {  // all of the prefetch is out after the first quarter of the step: a microsecond before it is needed
+#pragma unroll
+                    for (int j = s / 2 * ((BPT + 1) / 2); j < (s / 2 + 1) * ((BPT + 1) / 2) && j < BPT; ++j) rb[j] = pw[j * NTH];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const float a0 = valid ? cur[s >> 2][s & 3] : 0.f, a1 = valid ? cur[(s + 1) >> 2][(s + 1) & 3] : 0.f;
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[n], acc[n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[n], acc[n], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                b0 = n0, b1 = n1;
             }
         }
-        if (nk < 0) return false;
-        store_b(buf ^ 1);
+        PROF_T(q2);
+        buf ^= 1;
+#pragma unroll
+        for (int j = 0; j < BPT; ++j) Bs4[buf][j * NTH + tid] = rb[j];
+        PROF_T(q3);
         __syncthreads();
-        k = nk, kc = nkc, nb = nbn;
-        return true;
-    };
-    if (k >= 0) {
-        nb = s_nbr[k * TM + wid * 32 + i32];
-        load_a(raA, nb, 0);
-        load_b(k, 0);
-        store_b(0);
-        __syncthreads();
-        while (step(raA, raB, 0) && step(raB, raA, 1)) {
-        }
+        PROF_T(q4);
+        PROF_ADD(sg0, q0, q1);
+        PROF_ADD(sg1, q1, q2);
+        PROF_ADD(sg2, q2, q3);
+        PROF_ADD(sg3, q3, q4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
+        k = more ? nk : -1, kc = nkc, nb = nbn;
     }
+    PROF_T(pt2);
     // epilogue: C/D layout of a 32x32 block: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); block n, lane col i32 <-> column 4*i32 + n
     f32x4* Y4 = (f32x4*)Y;
 #pragma unroll
@@ -336,7 +408,20 @@ __global__ __launch_bounds__(NW * 64) void k_conv128_rows(const float* __restric
         const f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
         if (row < M_out) Y4[row * 32 + i32] = v;
     }
+#ifdef DD3D_CONV_PROF
+    if (lane == 0 && blockIdx.x < 1024) {  // [start, table done, loop done, end, steps | segment sums, wave steps | ..., HW_ID, XCC_ID]
+        long long* o = g_prof + ((int64_t)blockIdx.x * 4 + wid) * 8;
+        o[0] = pt0, o[1] = pt1, o[2] = pt2, o[3] = wall_clock64();
+        o[4] = __builtin_popcount(kmask) | (sg0 << 8) | (sg1 << 32), o[5] = __builtin_popcount(wmask) | (sg2 << 8) | (sg3 << 32);
+        o[6] = __builtin_amdgcn_s_getreg(4 | (31 << 11)), o[7] = __builtin_amdgcn_s_getreg(20 | (31 << 11));
+    }
+#endif
 }
+#ifdef DD3D_CONV_PROF
+}  // namespace
+DD3D_API int dd3d_prof_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(g_prof)); }
+namespace {
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Cin = Cout = 128 backward-weight: one workgroup per (row chunk, offset k) -> partial slab [128][128]
@@ -822,7 +907,8 @@ DD3D_API int dd3d_conv_fwd(const float* X, int64_t M_in, int Cin, const float* W
         const bool big = dbg_tile ? dbg_tile == 128 : M_out >= 128 * 512;
         if (big && dbg_rows) {
             const int64_t nt = ceil_div64(M_out, 128);
-            k_conv128_rows<4><<<dim3((unsigned)(ceil_div64(nt, 8) * 8)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, dbg_xcd, nullptr, nullptr);
+            k_conv128_rows<4><<<dim3((unsigned)(ceil_div64(nt, 8) * 8)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, dbg_xcd, nullptr, nullptr,
+                                                                                      nullptr, nullptr);
         } else if (big) {
             const int64_t nt = ceil_div64(M_out, 128);
             k_conv128<128, 2, 2><<<dim3((unsigned)(ceil_div64(nt, 8) * 8)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, dbg_xcd);
@@ -845,14 +931,15 @@ DD3D_API int dd3d_conv_fwd(const float* X, int64_t M_in, int Cin, const float* W
 DD3D_API int64_t dd3d_conv_schedule_blocks(int64_t M);
 DD3D_API int dd3d_conv_schedule_tile_rows(int64_t M);
 DD3D_API int dd3d_conv128_ordered(const float* X, int64_t M_in, const float* W, const int32_t* nbr, int64_t ld, int K, int64_t M_out, const int32_t* m_dev,
-                                  int mirror, const int32_t* perm, const int32_t* tile_map, float* Y, void* stream) {
+                                  int mirror, const int32_t* perm, const int32_t* tile_map, const int32_t* nbr_sorted, const uint32_t* tile_mask, float* Y,
+                                  void* stream) {
     if (M_out < 0 || M_in < 0 || K != 27 || ld < M_out) return DD3D_EARG;
     if (M_out >= (1ll << 31) / 128 * 16) return DD3D_ESIZE;
     if (M_out == 0) return 0;
-    if (!X || !W || !nbr || !Y || !perm || !tile_map) return DD3D_EARG;
+    if (!X || !W || !nbr || !Y || !perm || !tile_map || (nbr_sorted == nullptr) != (tile_mask == nullptr)) return DD3D_EARG;
     const unsigned nb = (unsigned)dd3d_conv_schedule_blocks(M_out);
     if (dd3d_conv_schedule_tile_rows(M_out) == 128)
-        k_conv128_rows<4><<<dim3(nb), 256, 0, (hipStream_t)stream>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, 0, perm, tile_map);
+        k_conv128_rows<4><<<dim3(nb), 256, 0, (hipStream_t)stream>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, 0, perm, tile_map, nbr_sorted, tile_mask);
     else  // small launches: 32-row tiles (see dd3d_conv_fwd), same schedule machinery
         k_conv128<32, 1, 4><<<dim3(nb), 256, 0, (hipStream_t)stream>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, 0, perm, tile_map);
     DD3D_CHECK_LAUNCH();

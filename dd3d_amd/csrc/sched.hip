@@ -69,11 +69,11 @@ __global__ __launch_bounds__(1024) void k_row_keys(const int* __restrict__ nbr, 
 __global__ __launch_bounds__(1024) void k_row_scatter(const unsigned* __restrict__ keys, int M_bound, const int* __restrict__ m_dev,
                                                       const int* __restrict__ hist, int* __restrict__ fill, int* __restrict__ ends,
                                                       int* __restrict__ perm, unsigned* __restrict__ sorted_keys, int* __restrict__ perm_refine,
-                                                      int refine_min) {
+                                                      int refine_min, int* __restrict__ inv) {
     __shared__ int s_cnt[NB], s_base[NB];
     __shared__ int s_w[16];
     const int M = m_dev ? min(*m_dev, M_bound) : M_bound;
-    if (perm_refine && M >= refine_min) perm = perm_refine;  // a second level follows (decided by the TRUE row count)
+    if (perm_refine && M >= refine_min) perm = perm_refine, inv = nullptr;  // a second level follows (decided by the TRUE row count)
     const int i0 = blockIdx.x * 4096;
     if (i0 >= M) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -125,6 +125,25 @@ __global__ __launch_bounds__(1024) void k_row_scatter(const unsigned* __restrict
         perm[pos] = i0 + j * 1024 + tid;
         sorted_keys[pos] = key[j];
     }
+    // position of every row in the pattern order (k_table_permute scatters the table's columns there); not with a second level
+    if (inv) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (bucket[j] >= 0) inv[i0 + j * 1024 + tid] = s_base[bucket[j]] + rank[j];
+    }
+}
+
+// The kernel map in pattern order, nbr_sorted[k][pos] = nbr[k][perm[pos]]: the table columns a tile of the sorted launch needs are then
+// contiguous (gathered per tile they cost every workgroup a dozen microseconds of scattered 4-byte reads before its first MFMA).
+// Coalesced reads; 4-byte writes that land in runs wherever neighbouring rows share a bucket.  One workgroup per (256 rows, offset).
+__global__ __launch_bounds__(256) void k_table_permute(const int* __restrict__ nbr, int64_t ld, int M_bound, const int* __restrict__ m_dev,
+                                                       const int* __restrict__ inv, int refine_min, int* __restrict__ nbr_sorted) {
+    const int M = m_dev ? min(*m_dev, M_bound) : M_bound;
+    if (refine_min > 0 && M >= refine_min) return;  // a second sort level ran: the table stays as it is (tile_mask bit 31 says so)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const int64_t col = (int64_t)blockIdx.y * ld;
+    nbr_sorted[col + inv[i]] = nbr[col + i];
 }
 
 // Second level, for launches of at least 262144 rows under a bound of 2^20 or more (volumetric clouds; planar ones have none of these 12
@@ -199,11 +218,13 @@ __global__ __launch_bounds__(1024) void k_bucket_refine(const int* __restrict__ 
 // 40 us to get through -- hence a kernel of its own, 64 tiles per workgroup)
 template <int TR>  // rows per tile: 128 (k_conv128_rows) or 32 (k_conv128<32,1,4>)
 __global__ __launch_bounds__(64) void k_tile_cost(const unsigned* __restrict__ sorted_keys, int M_bound, const int* __restrict__ m_dev,
-                                                  const unsigned* __restrict__ refined_keys, int refine_min, int* __restrict__ cost) {
+                                                  const unsigned* __restrict__ refined_keys, int refine_min, int* __restrict__ cost,
+                                                  unsigned* __restrict__ tile_mask) {
     const int M = m_dev ? min(*m_dev, M_bound) : M_bound;
-    if (refined_keys && M >= refine_min) sorted_keys = refined_keys;
+    const bool refined = refined_keys && M >= refine_min;
+    if (refined) sorted_keys = refined_keys;
     const int ntile = (M + TR - 1) / TR, t = blockIdx.x * 64 + threadIdx.x;
-    if (t >= ntile || t >= 2048) return;
+    if (t >= ntile || (t >= 2048 && !tile_mask)) return;
     unsigned u = 0;
     const uint4* k4 = (const uint4*)(sorted_keys + (int64_t)t * TR);   // TR * 4 B aligned: the workspace carve is 256-B aligned
     const int n = min(TR, M - t * TR);
@@ -216,14 +237,19 @@ __global__ __launch_bounds__(64) void k_tile_cost(const unsigned* __restrict__ s
     } else {
         for (int i = 0; i < n; ++i) u |= sorted_keys[(int64_t)t * TR + i];
     }
-    cost[t] = __popc(u);
+    if (t < 2048) cost[t] = __popc(u);
+    // the offsets some row of the tile has: all its workgroup needs to read of the table (bit 31: the table was NOT permuted, see the launcher)
+    if (tile_mask) tile_mask[t] = u | (refined ? 0x80000000u : 0u);
 }
 
 template <int TR>
 __global__ __launch_bounds__(1024) void k_tile_schedule(const int* __restrict__ g_cost, int M_bound, const int* __restrict__ m_dev, int n_blocks,
                                                         int* __restrict__ tile_map) {
     constexpr int MAXT = 2048;  // two tiles per thread
-    __shared__ __align__(16) int s_cost[MAXT];
+    __shared__ short s_cnt[28][32], s_base[28][32];
+    __shared__ int s_tot[28];
+    __shared__ __align__(16) int s_load[256];
+    __shared__ short s_tile[MAXT], s_rcost[MAXT];
     const int tid = threadIdx.x;
     const int M = m_dev ? min(*m_dev, M_bound) : M_bound;
     const int ntile = (M + TR - 1) / TR;
@@ -233,38 +259,96 @@ __global__ __launch_bounds__(1024) void k_tile_schedule(const int* __restrict__ 
         for (int t = tid; t < ntile && t < n_blocks; t += 1024) tile_map[t] = t;
         return;
     }
-    int cost[2];
+    for (int i = tid; i < 28 * 32; i += 1024) (&s_cnt[0][0])[i] = 0;
+    __syncthreads();
+    // rank of tile t in (cost descending, index ascending): a counting sort over the 28 possible costs.  Chunk q = 64 consecutive tiles
+    // (one wave, ballots per cost value); s_cnt[v][q] = tiles of cost v in chunk q.
+    const int lane = tid & 63, w = tid >> 6;
+    int cost[2], within[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int t = tid + j * 1024;
-        const int c = t < ntile ? g_cost[t] : -1;
+        const int t = tid + j * 1024, q = j * 16 + w;
+        const int c = t < ntile ? min(g_cost[t], 27) : -1;
         cost[j] = c;
-        s_cost[t] = c;
+        within[j] = 0;
+        for (unsigned long long rest = __ballot(c >= 0); rest;) {  // one pass per distinct cost of the chunk
+            const int v = __shfl(c, __builtin_ctzll(rest), 64);
+            const unsigned long long m = __ballot(c == v);
+            if (c == v) within[j] = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) s_cnt[v][q] = (short)__popcll(m);
+            rest &= ~m;
+        }
     }
     __syncthreads();
-    const int4* s_cost4 = (const int4*)s_cost;   // slots beyond ntile hold -1: they never outrank a tile (cost >= 0)
+    // s_base[v][q] = tiles ranked before the first cost-v tile of chunk q: all tiles of a higher cost, and the cost-v tiles of earlier chunks
+    if (tid < 28) {
+        int tot = 0;
+        for (int q = 0; q < 32; ++q) tot += s_cnt[tid][q];
+        s_tot[tid] = tot;
+    }
+    __syncthreads();
+    if (tid < 28) {
+        int before = 0;
+        for (int v = 27; v > tid; --v) before += s_tot[v];
+        for (int q = 0; q < 32; ++q) {
+            s_base[tid][q] = (short)before;
+            before += s_cnt[tid][q];
+        }
+    }
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int t = tid + j * 1024, c = cost[j];
         if (t >= ntile) continue;
-        int rank = 0;
-        for (int u4 = 0; u4 < (ntile + 3) / 4; ++u4) {
-            const int4 q = s_cost4[u4];
-            const int u = u4 * 4;
-            rank += (q.x > c) || (q.x == c && u < t);
-            rank += (q.y > c) || (q.y == c && u + 1 < t);
-            rank += (q.z > c) || (q.z == c && u + 2 < t);
-            rank += (q.w > c) || (q.w == c && u + 3 < t);
+        const int rank = s_base[c][j * 16 + w] + within[j];
+        s_tile[rank] = (short)t;
+        s_rcost[rank] = (short)c;
+    }
+    __syncthreads();
+    // Round r deals the tiles ranked [256 r, 256 r + 256) to the 256 CUs (workgroup 256 r + c runs on CU c): the heaviest of them to the CU
+    // with the least work so far, the next to the second least loaded, ... (ties by CU index).  Rounds 0 and 1 come out as the snake
+    // (forwards, backwards); from round 2 on the match follows the loads the earlier rounds left, which the snake ignored.
+    const int c = tid & 255;
+    int load = 0;
+    // (rounds 0 and 1 in closed form: CU c takes rank c, then -- the loads now descending in c -- rank 256 + (255 - c))
+    if (tid < 256) {
+        if (c < ntile) {
+            if (c < n_blocks) tile_map[c] = s_tile[c];
+            load = s_rcost[c];
         }
-        const int r = rank >> 8, pos = rank & 255;
-        const int b = r * 256 + ((r & 1) ? 255 - pos : pos);
-        if (b < n_blocks) tile_map[b] = t;
+        const int i = 256 + 255 - c;
+        if (i < ntile) {
+            if (256 + c < n_blocks) tile_map[256 + c] = s_tile[i];
+            load += s_rcost[i];
+        }
+    }
+    for (int r = 2; r * 256 < ntile; ++r) {
+        if (tid < 256) s_load[c] = load;
+        __syncthreads();
+        if (tid < 256) {
+            int pos = 0;
+            const int4* l4 = (const int4*)s_load;
+            for (int u4 = 0; u4 < 64; ++u4) {
+                const int4 q = l4[u4];
+                const int u = u4 * 4;
+                pos += (q.x < load) || (q.x == load && u < c);
+                pos += (q.y < load) || (q.y == load && u + 1 < c);
+                pos += (q.z < load) || (q.z == load && u + 2 < c);
+                pos += (q.w < load) || (q.w == load && u + 3 < c);
+            }
+            const int i = r * 256 + pos;
+            if (i < ntile) {
+                if (r * 256 + c < n_blocks) tile_map[r * 256 + c] = s_tile[i];
+                load += s_rcost[i];
+            }
+        }
+        __syncthreads();
     }
 }
 
 struct SchedWs {
     unsigned *keys, *sorted_keys;
-    int *hist, *fill, *ends, *cost, *perm_tmp;  // hist and fill are adjacent: one memset
+    int *hist, *fill, *ends, *cost, *perm_tmp, *inv;  // hist and fill are adjacent: one memset
 };
 constexpr int64_t REFINE_MIN = 1 << 18;         // true rows from which the second sort level runs (below, a bucket holds too few rows to gain)
 constexpr int64_t REFINE_LAUNCH_MIN = 1 << 20;  // row bound from which its kernel is launched at all (an idle node still costs the chain ~15 us)
@@ -285,6 +369,7 @@ int64_t carve(int64_t M, void* ws, SchedWs* out) {
     w.ends = (int*)take(NB * 4);
     w.cost = (int*)take(2048 * 4);
     w.perm_tmp = M >= REFINE_LAUNCH_MIN ? (int*)take(n * 4) : nullptr;
+    w.inv = (int*)take(n * 4);
     if (out) *out = w;
     return off;
 }
@@ -300,13 +385,15 @@ DD3D_API int64_t dd3d_conv_schedule_blocks(int64_t M) { return ceil_div64(ceil_d
 DD3D_API int64_t dd3d_conv_schedule_ws_bytes(int64_t M) { return carve(M, nullptr, nullptr); }
 
 // perm[M] (int32): the rows in pattern order; tile_map[dd3d_conv_schedule_blocks(M)] (int32): workgroup -> tile of that order, or -1.
+// Optional (both or neither): nbr_sorted[K][ld] = the kernel map with its columns in pattern order, tile_mask[ceil(M / tile rows)] = the
+// offsets present in each tile -- with them a workgroup of dd3d_conv128_ordered reads its part of the table in a few coalesced loads.
 // M is a bound when m_dev is given (rows beyond *m_dev sort last and get no tile).
-DD3D_API int dd3d_conv_schedule(const int32_t* nbr, int64_t ld, int K, int64_t M, const int32_t* m_dev, int32_t* perm, int32_t* tile_map, void* ws,
-                                int64_t ws_bytes, void* stream) {
+DD3D_API int dd3d_conv_schedule(const int32_t* nbr, int64_t ld, int K, int64_t M, const int32_t* m_dev, int32_t* perm, int32_t* tile_map,
+                                int32_t* nbr_sorted, uint32_t* tile_mask, void* ws, int64_t ws_bytes, void* stream) {
     if (M < 0 || K <= 0 || K > 27 || ld < M) return DD3D_EARG;
     if (M >= (1ll << 31) - 256) return DD3D_ESIZE;
     if (M == 0) return 0;
-    if (!nbr || !perm || !tile_map) return DD3D_EARG;
+    if (!nbr || !perm || !tile_map || (nbr_sorted == nullptr) != (tile_mask == nullptr) || nbr_sorted == nbr) return DD3D_EARG;
     if (!ws || ws_bytes < dd3d_conv_schedule_ws_bytes(M)) return DD3D_EWS;
     SchedWs w;
     carve(M, ws, &w);
@@ -315,18 +402,22 @@ DD3D_API int dd3d_conv_schedule(const int32_t* nbr, int64_t ld, int K, int64_t M
     DD3D_HIP(hipMemsetAsync(w.hist, 0, 2 * NB * 4, st));
     k_row_keys<<<dim3((unsigned)ceil_div64(M, 1024)), 1024, 0, st>>>(nbr, ld, K, (int)M, m_dev, w.keys, w.hist);
     const bool refine = M >= REFINE_LAUNCH_MIN;  // M may be a bound: the kernels take the second level only when the TRUE count reaches REFINE_MIN
+    // (with a second sort level the table is not permuted: dd3d_conv128_ordered then gathers it through perm, told by tile_mask bit 31)
     k_row_scatter<<<dim3(nwg), 1024, 0, st>>>(w.keys, (int)M, m_dev, w.hist, w.fill, w.ends, perm, w.sorted_keys, refine ? w.perm_tmp : nullptr,
-                                              (int)REFINE_MIN);
+                                              (int)REFINE_MIN, nbr_sorted ? w.inv : nullptr);
+    if (nbr_sorted)
+        k_table_permute<<<dim3((unsigned)ceil_div64(M, 256), (unsigned)K), 256, 0, st>>>(nbr, ld, (int)M, m_dev, w.inv, refine ? (int)REFINE_MIN : 0, nbr_sorted);
     if (refine)
         k_bucket_refine<<<dim3(512), 1024, 0, st>>>(w.ends, w.perm_tmp, w.sorted_keys, perm, w.keys /* done with: reused */, (int)M, m_dev, (int)REFINE_MIN);
     // the placement uses the costs of up to 2048 tiles (of the TRUE row count: M may be a bound)
     const int nb = (int)dd3d_conv_schedule_blocks(M);
-    const int64_t tr = dd3d_conv_schedule_tile_rows(M), nt = ceil_div64(M, tr) < 2048 ? ceil_div64(M, tr) : 2048;
+    const int64_t tr = dd3d_conv_schedule_tile_rows(M), nt = (ceil_div64(M, tr) < 2048 || tile_mask) ? ceil_div64(M, tr) : 2048;
     if (tr == 128) {
-        k_tile_cost<128><<<dim3((unsigned)ceil_div64(nt, 64)), 64, 0, st>>>(w.sorted_keys, (int)M, m_dev, refine ? w.keys : nullptr, (int)REFINE_MIN, w.cost);
+        k_tile_cost<128><<<dim3((unsigned)ceil_div64(nt, 64)), 64, 0, st>>>(w.sorted_keys, (int)M, m_dev, refine ? w.keys : nullptr, (int)REFINE_MIN, w.cost,
+                                                                             tile_mask);
         k_tile_schedule<128><<<1, 1024, 0, st>>>(w.cost, (int)M, m_dev, nb, tile_map);
     } else {
-        k_tile_cost<32><<<dim3((unsigned)ceil_div64(nt, 64)), 64, 0, st>>>(w.sorted_keys, (int)M, m_dev, nullptr, 0, w.cost);
+        k_tile_cost<32><<<dim3((unsigned)ceil_div64(nt, 64)), 64, 0, st>>>(w.sorted_keys, (int)M, m_dev, nullptr, 0, w.cost, tile_mask);
         k_tile_schedule<32><<<1, 1024, 0, st>>>(w.cost, (int)M, m_dev, nb, tile_map);
     }
     DD3D_CHECK_LAUNCH();

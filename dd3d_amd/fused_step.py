@@ -159,13 +159,18 @@ class _Pass:
         if use_sched:
             perm1 = _empty((M1,), dev, _I32)
             tmap1 = _empty((int(L.lib.dd3d_conv_schedule_blocks(M1)),), dev, _I32)
+            # the 128-row kernel also takes the table in pattern order and the offsets of every tile (the 32-row one gathers through perm)
+            tr = int(L.lib.dd3d_conv_schedule_tile_rows(M1))
+            k1s = _empty((27, ld1), dev, _I32) if tr == 128 else None
+            tmask1 = _empty(((M1 + tr - 1) // tr,), dev, _I32) if tr == 128 else None
             self.side.wait_event(ev_maps)
             with torch.cuda.stream(self.side):
                 ws = L.workspace(int(L.lib.dd3d_conv_schedule_ws_bytes(M1)), dev)
-                L.call("dd3d_conv_schedule", L.ptr(k1), ld1, 27, M1, c1, L.ptr(perm1), L.ptr(tmap1), L.ptr(ws), ws.numel(), L.stream())
-            self.sched = (perm1, tmap1)
+                L.call("dd3d_conv_schedule", L.ptr(k1), ld1, 27, M1, c1, L.ptr(perm1), L.ptr(tmap1), L.ptr(k1s), L.ptr(tmask1), L.ptr(ws), ws.numel(),
+                       L.stream())
+            self.sched = (perm1, tmap1, k1s, tmask1)
             torch.cuda.current_stream(dev).wait_stream(self.side)
-            L.call("dd3d_conv128_ordered", L.ptr(P0), M1, L.ptr(W1), L.ptr(k1), ld1, 27, M1, c1, 0, L.ptr(self.sched[0]), L.ptr(self.sched[1]),
+            L.call("dd3d_conv128_ordered", L.ptr(P0), M1, L.ptr(W1), L.ptr(k1), ld1, 27, M1, c1, 0, L.ptr(perm1), L.ptr(tmap1), L.ptr(k1s), L.ptr(tmask1),
                    L.ptr(Y1), st)
         else:
             L.call("dd3d_conv_fwd", L.ptr(P0), M1, 128, L.ptr(W1), 128, L.ptr(k1), ld1, 27, M1, c1, 0, L.ptr(Y1), st)
@@ -214,7 +219,7 @@ class _Pass:
         gP0 = _empty((M1, 128), dev)
         if self.sched is not None:
             L.call("dd3d_conv128_ordered", L.ptr(gY1), M1, L.ptr(W1t), L.ptr(k1), ld1, 27, M1, c1, 1, L.ptr(self.sched[0]), L.ptr(self.sched[1]),
-                   L.ptr(gP0), st)
+                   L.ptr(self.sched[2]), L.ptr(self.sched[3]), L.ptr(gP0), st)
         else:
             L.call("dd3d_conv_bwd_data", L.ptr(gY1), M1, c1, 128, L.ptr(W1t), 128, L.ptr(k1), ld1, 27, L.ptr(gP0), st)
         if after and not defer:

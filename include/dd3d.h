@@ -123,20 +123,23 @@ int dd3d_conv_fwd(const float* X, int64_t M_in, int Cin, const float* W, int Cou
 /* Launch schedule of the Cin = Cout = 128 convolution over one kernel map: perm[M] = the rows sorted (stable radix sort) by their K-bit
  * pattern of present offsets, so that the 32 rows one wave multiplies together share a pattern and absent offsets are skipped for the
  * whole block; tile_map[dd3d_conv_schedule_blocks(M)] = workgroup -> tile (dd3d_conv_schedule_tile_rows(M) rows) of that order (-1 = none), the tiles ranked by
- * cost and dealt to the CUs in a snake so that the most loaded CU carries the average.  M is a bound when m_dev is given.  One
- * schedule serves the forward and the mirrored launch.  No counterpart in MinkowskiEngine (its gather-GEMM-scatter compacts per
- * offset instead); serves MEConv.py:224 like dd3d_conv_fwd. */
+ * cost and dealt to the CUs round by round, heaviest tile to the least loaded CU, so that the most loaded CU carries the average.
+ * Optional outputs (both or neither): nbr_sorted[K][ld] = the kernel map with its columns in pattern order, tile_mask[ceil(M / tile rows)]
+ * = the offsets present in each tile; with them a workgroup of dd3d_conv128_ordered reads its part of the table coalesced.
+ * M is a bound when m_dev is given.  One schedule serves the forward and the mirrored launch.  No counterpart in MinkowskiEngine (its
+ * gather-GEMM-scatter compacts per offset instead); serves MEConv.py:224 like dd3d_conv_fwd. */
 int dd3d_conv_schedule_tile_rows(int64_t M); /* 128 from 65536 rows on (k_conv128_rows), 32 below (k_conv128<32,1,4>) */
 int64_t dd3d_conv_schedule_blocks(int64_t M);
 int64_t dd3d_conv_schedule_ws_bytes(int64_t M);
-int dd3d_conv_schedule(const int32_t* nbr, int64_t ld, int K, int64_t M, const int32_t* m_dev, int32_t* perm, int32_t* tile_map, void* ws,
-                       int64_t ws_bytes, void* stream);
+int dd3d_conv_schedule(const int32_t* nbr, int64_t ld, int K, int64_t M, const int32_t* m_dev, int32_t* perm, int32_t* tile_map,
+                       int32_t* nbr_sorted, uint32_t* tile_mask, void* ws, int64_t ws_bytes, void* stream);
 
 /* dd3d_conv_fwd for Cin = Cout = 128, K = 27 along a schedule: bit-identical output (a row's sum does not depend on the rows it shares
  * a block with), fewer all-zero rows through the matrix cores, even load over the CUs.
  * replaces: ConvolutionForwardGPU / ConvolutionBackwardGPU (input gradient, mirror = 1 with the transposed kernel), MEConv.py:224 */
 int dd3d_conv128_ordered(const float* X, int64_t M_in, const float* W, const int32_t* nbr, int64_t ld, int K, int64_t M_out, const int32_t* m_dev,
-                         int mirror, const int32_t* perm, const int32_t* tile_map, float* Y, void* stream);
+                         int mirror, const int32_t* perm, const int32_t* tile_map, const int32_t* nbr_sorted, const uint32_t* tile_mask, float* Y,
+                         void* stream);
 
 /* dd3d_conv_fwd for Cin = Cout = 128, K = 27 for launches of few rows (the synthetic rows of the second-order pass): the offsets of
  * every 32-row tile are dealt over up to nine workgroups (count chosen from the true row count), partial tiles go to ws and are added

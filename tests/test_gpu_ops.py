@@ -439,18 +439,38 @@ def test_scheduled_conv128_is_bit_identical(M, bound):
     perm = torch.full((bound,), -7, dtype=torch.int32, device=d)
     tmap = torch.full((nblk,), -7, dtype=torch.int32, device=d)
     ws = torch.empty(int(L.lib.dd3d_conv_schedule_ws_bytes(bound)), dtype=torch.uint8, device=d)
-    L.call("dd3d_conv_schedule", L.ptr(nbr), bound, 27, bound, L.ptr(m_dev), L.ptr(perm), L.ptr(tmap), L.ptr(ws), ws.numel(), L.stream())
+    tr = int(L.lib.dd3d_conv_schedule_tile_rows(bound))   # 128-row tiles from 65536 rows on, 32-row tiles below
+    # optional outputs: the table in pattern order and the offsets of every tile
+    nbr_s = torch.full((27, bound), -9, dtype=torch.int32, device=d)
+    tmask = torch.zeros(((bound + tr - 1) // tr,), dtype=torch.int32, device=d)
+    L.call("dd3d_conv_schedule", L.ptr(nbr), bound, 27, bound, L.ptr(m_dev), L.ptr(perm), L.ptr(tmap), L.ptr(nbr_s), L.ptr(tmask), L.ptr(ws),
+           ws.numel(), L.stream())
     assert sorted(perm[:M].tolist()) == list(range(M))
     tiles = [t for t in tmap.tolist() if t >= 0]
-    tr = int(L.lib.dd3d_conv_schedule_tile_rows(bound))   # 128-row tiles from 65536 rows on, 32-row tiles below
     assert sorted(tiles) == list(range((M + tr - 1) // tr)) and min(tmap.tolist()) >= -1
+    nt = (M + tr - 1) // tr
+    pres = (nbr[:, perm[:M].long()] >= 0)
+    pres = torch.cat([pres, pres.new_zeros(27, nt * tr - M)], 1).reshape(27, nt, tr).any(2)
+    want_mask = (pres.long() << torch.arange(27, device=d)[:, None]).sum(0)
+    assert torch.equal(tmask[:nt].long() & 0x7ffffff, want_mask)
+    if not bool((tmask[:nt] < 0).any()):   # bit 31: a second sort level ran and the table was left alone
+        assert torch.equal(nbr_s[:, :M], nbr[:, perm[:M].long()])
+    else:
+        assert bool((tmask[:nt] < 0).all())
+    # a schedule without the optional outputs is the same schedule up to the order inside a bucket: same tiles, same result
+    perm_b, tmap_b = torch.empty_like(perm), torch.empty_like(tmap)
+    L.call("dd3d_conv_schedule", L.ptr(nbr), bound, 27, bound, L.ptr(m_dev), L.ptr(perm_b), L.ptr(tmap_b), None, None, L.ptr(ws), ws.numel(), L.stream())
+    assert sorted(perm_b[:M].tolist()) == list(range(M))
     for mirror in (0, 1):
         Y = torch.full((bound, 128), 7.0, device=d)
         Y2 = torch.full((bound, 128), 7.0, device=d)
+        Y3 = torch.full((bound, 128), 7.0, device=d)
         L.call("dd3d_conv_fwd", L.ptr(X), bound, 128, L.ptr(W), 128, L.ptr(nbr), bound, 27, bound, L.ptr(m_dev), mirror, L.ptr(Y), L.stream())
         L.call("dd3d_conv128_ordered", L.ptr(X), bound, L.ptr(W), L.ptr(nbr), bound, 27, bound, L.ptr(m_dev), mirror, L.ptr(perm), L.ptr(tmap),
-               L.ptr(Y2), L.stream())
-        assert torch.equal(Y, Y2)
+               L.ptr(nbr_s), L.ptr(tmask), L.ptr(Y2), L.stream())
+        L.call("dd3d_conv128_ordered", L.ptr(X), bound, L.ptr(W), L.ptr(nbr), bound, 27, bound, L.ptr(m_dev), mirror, L.ptr(perm_b), L.ptr(tmap_b),
+               None, None, L.ptr(Y3), L.stream())
+        assert torch.equal(Y, Y2) and torch.equal(Y, Y3)
         assert bool((Y[M:] == 7.0).all())   # rows beyond the device-side count are not touched
     # the patterns are grouped: fewer (32-row block, offset) products than in row order
     present = (nbr[:, :M] >= 0)
@@ -534,10 +554,13 @@ def test_large_conv128_rows_kernel_vs_fp64_oracle(M, bound, mirror):
     perm = torch.empty((bound,), dtype=torch.int32, device=d)
     tmap = torch.empty((int(L.lib.dd3d_conv_schedule_blocks(bound)),), dtype=torch.int32, device=d)
     ws = torch.empty(int(L.lib.dd3d_conv_schedule_ws_bytes(bound)), dtype=torch.uint8, device=d)
-    L.call("dd3d_conv_schedule", L.ptr(nbr_d), bound, 27, bound, L.ptr(m_dev), L.ptr(perm), L.ptr(tmap), L.ptr(ws), ws.numel(), L.stream())
+    nbr_s = torch.empty_like(nbr_d)
+    tmask = torch.empty(((bound + 127) // 128,), dtype=torch.int32, device=d)
+    L.call("dd3d_conv_schedule", L.ptr(nbr_d), bound, 27, bound, L.ptr(m_dev), L.ptr(perm), L.ptr(tmap), L.ptr(nbr_s), L.ptr(tmask), L.ptr(ws),
+           ws.numel(), L.stream())
     Y2 = torch.full((bound, 128), 7.0, device=d)
     L.call("dd3d_conv128_ordered", L.ptr(X_d), bound, L.ptr(W_d), L.ptr(nbr_d), bound, 27, bound, L.ptr(m_dev), mirror, L.ptr(perm), L.ptr(tmap),
-           L.ptr(Y2), L.stream())
+           L.ptr(nbr_s), L.ptr(tmask), L.ptr(Y2), L.stream())
     e2 = rel_err(Y2[:M], ref)
     print(f"conv128_rows M={M} mirror={mirror}: plain {e1:.2e} ordered {e2:.2e}")
     assert e1 < 2e-5 and e2 < 2e-5

@@ -37,13 +37,14 @@ for name, coords, B in (("real", b["coordinates"], 2560), ("syn", sc, 100), ("me
     # scheduled variant (dd3d_conv_schedule: pattern-sorted rows + balanced tile placement); must be bit-identical
     nblk = int(L.lib.dd3d_conv_schedule_blocks(M))
     perm = torch.empty(M, dtype=torch.int32, device=dev)
+    nbr_s = torch.empty_like(nbr); tmask = torch.empty((M + 31) // 32, dtype=torch.int32, device=dev)
     tmap = torch.empty(nblk, dtype=torch.int32, device=dev)
     ws = torch.empty(int(L.lib.dd3d_conv_schedule_ws_bytes(M)), dtype=torch.uint8, device=dev)
     Y2 = torch.empty_like(Y)
     def sched():
-        L.call("dd3d_conv_schedule", L.ptr(nbr), ld, 27, M, None, L.ptr(perm), L.ptr(tmap), L.ptr(ws), ws.numel(), L.stream())
+        L.call("dd3d_conv_schedule", L.ptr(nbr), ld, 27, M, None, L.ptr(perm), L.ptr(tmap), L.ptr(nbr_s), L.ptr(tmask), L.ptr(ws), ws.numel(), L.stream())
     def run2():
-        L.call("dd3d_conv128_ordered", L.ptr(X), M, L.ptr(W), L.ptr(nbr), ld, 27, M, None, 0, L.ptr(perm), L.ptr(tmap), L.ptr(Y2), L.stream())
+        L.call("dd3d_conv128_ordered", L.ptr(X), M, L.ptr(W), L.ptr(nbr), ld, 27, M, None, 0, L.ptr(perm), L.ptr(tmap), L.ptr(nbr_s), L.ptr(tmask), L.ptr(Y2), L.stream())
     sched(); run2(); torch.cuda.synchronize()
     assert sorted(perm.tolist()) == list(range(M)), "perm is not a permutation"
     tl = [t for t in tmap.tolist() if t >= 0]
