@@ -1,8 +1,6 @@
 #!/bin/bash
 # A/B of two builds of the library on tools/convbench.py: usage tools/ab.sh <other.so>   (run from the repo root on the GPU box)
+# The comparison build is loaded through DD3D_LIB (dd3d_amd/_lib.py); the product library is never touched.
 set -o pipefail
-cp dd3d_amd/libdd3d_hip.so /tmp/lib_new.so
 echo "== new"; timeout -k 10 120 python tools/convbench.py || exit 1
-cp "$1" dd3d_amd/libdd3d_hip.so
-echo "== base"; timeout -k 10 120 python tools/convbench.py || exit 1
-cp /tmp/lib_new.so dd3d_amd/libdd3d_hip.so
+echo "== base"; DD3D_LIB="$1" timeout -k 10 120 python tools/convbench.py || exit 1
