@@ -181,15 +181,18 @@ def test_graph_replay_is_bitwise_the_eager_step(metric, classes):
     assert fg._graph is not None and len(sizes) > 1  # the graph really replayed over batches of different sizes
 
 
-@pytest.mark.parametrize("metric", ["modmse", "ours"])
-def test_fused_3d_point_clouds_vs_oracle(metric):
-    """ModelNet/ShapeNet-shaped case (BASELINE configs 4-5 in small): real data given as 3-D point clouds in [-1,1]^3, voxel size
-    0.05, all 27 kernel offsets active, 300-point clouds (the 1024-point LDS map builder), num_classes / dense_extent keyword
-    extensions -- graph replay and eager step against the CPU oracle: loss and xyz gradient within 1e-4, then graph == eager bitwise."""
+@pytest.mark.parametrize("metric,shape", [("modmse", "cfg4"), ("ours", "cfg4"), ("modmse", "cfg5"), ("ours", "cfg5")])
+def test_fused_3d_point_clouds_vs_oracle(metric, shape):
+    """ModelNet/ShapeNet-shaped cases (BASELINE configs 4-5 in small): real data given as 3-D point clouds in [-1,1]^3, all 27 kernel
+    offsets active, num_classes / dense_extent keyword extensions -- graph replay and eager step against the CPU oracle: loss and xyz
+    gradient within 1e-4, then graph == eager bitwise.
+      cfg4: voxel size 0.05, 300-point clouds (the LDS map builder, at most 1024 points per cloud), dense extent 16^3;
+      cfg5: voxel size 0.02, 2048-point clouds (too large for the LDS builder: the call-by-call coordinate manager, captured into the
+            graph with bound-sized launches all the same), dense extent 26^3 -- a 2.25 M-column classifier per class."""
     from dd3d_amd.fused_step import FusedDistiller
     from dd3d_amd.models.MEConv import MEConvExp
     from dd3d_amd.synthetic import shell_clouds
-    nclass, per, ipc, npts, q, ext, lr = 3, 6, 2, 300, 0.05, (16, 16, 16), 1e-5
+    nclass, per, ipc, npts, q, ext, lr = (3, 6, 2, 300, 0.05, (16, 16, 16), 1e-5) if shape == "cfg4" else (3, 4, 2, 2048, 0.02, (26, 26, 26), 1e-6)
     clouds = shell_clouds(nclass * per, npts, seed=21)
     idx = [list(range(c * per, (c + 1) * per)) for c in range(nclass)]
     g = torch.Generator().manual_seed(4)
@@ -224,6 +227,8 @@ def test_fused_3d_point_clouds_vs_oracle(metric):
             assert rel_err(fe.image_syn, osyn) < 1e-5
     fg.check()
     assert fg._graph is not None and fg.row_counts()[0][0] > 3000
+    from dd3d_amd.sparse import CloudCoordinateManager
+    assert isinstance(fg.last["passes"][0].cm, CloudCoordinateManager) == (shape == "cfg4")
 
 
 def _oracle_net():
