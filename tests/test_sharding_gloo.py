@@ -59,3 +59,77 @@ def test_owned_classes_partition_any_world():
         assert seen == list(range(10))
     with pytest.raises(ValueError):
         owned_classes(10, 3, 2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Second sharding level: the real batch of ONE class split over two ranks
+# ---------------------------------------------------------------------------------------------------------------------
+def _gw_real_oracle(net, clouds, label, q, min_corner=None, n_total=None):
+    """Parameter gradients of the cross entropy over ``clouds`` (mnist_distill.py:344-350) with the CPU oracle, fp64.  ``min_corner``
+    replaces the batch's own minimum stride-4 coordinate in dense() (MEConv.py:251-254 takes it over the WHOLE batch); ``n_total``
+    replaces the batch size in the mean of the cross entropy."""
+    from oracle import minkowski_ref as ME
+    from oracle import ref_model as R
+    lab = torch.full((len(clouds),), label, dtype=torch.long)
+    batch = R.collate([R.syn_item(c, lab[i]) for i, c in enumerate(clouds)])
+    batch["coordinates"], batch["features"] = batch["coordinates"].double(), batch["features"].double()
+    x = R.create_input_batch(batch, True, device="cpu", quantization_size=q)
+    out = net.features(x.sparse())
+    own = out.C.min(0, keepdim=True)[0][:, 1:]
+    corner = own if min_corner is None else min_corner
+    dense = out.dense(shape=torch.Size([len(clouds), 128, *net.dense_extent]), min_coordinate=corner)[0]
+    logits = net.classifier(dense.view(-1, net.n_dense))
+    ce = torch.nn.functional.cross_entropy(logits, lab, reduction="sum") / (n_total or len(clouds))
+    return [g.detach() for g in torch.autograd.grad(ce, list(net.parameters()))], own
+
+
+def _split_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from detgen import det_state_dict
+    from oracle import ref_model as R
+    from dd3d_amd.synthetic import shell_clouds
+    torch.set_num_threads(2)
+    nclass, ext, vox = 3, (12, 12, 12), 0.05
+    net = R.MEConvExp(3, nclass, num_classes=nclass, dense_extent=ext)
+    net.load_state_dict(det_state_dict(net, "net.split"))
+    net = net.double().train()
+    clouds = [c.double() for c in shell_clouds(6, 120, seed=5)]
+    clouds[3] = clouds[3] * 0.5 - 0.45          # one small cloud in the low corner: only ITS half of the batch sees the batch minimum
+    whole, corner = _gw_real_oracle(net, clouds, 1, vox)
+    mine = clouds[rank::world]
+    part, own = _gw_real_oracle(net, mine, 1, vox, min_corner=corner, n_total=len(clouds))
+    naive, _ = _gw_real_oracle(net, mine, 1, vox, n_total=len(clouds))        # the half batch placed by its OWN minimum corner
+    flat = torch.cat([g.reshape(-1) for g in part])
+    flat_naive = torch.cat([g.reshape(-1) for g in naive])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)                                # what RCCL does with the compact gw_real lists
+    dist.all_reduce(flat_naive, op=dist.ReduceOp.SUM)
+    ref = torch.cat([g.reshape(-1) for g in whole])
+    err = float((flat - ref).abs().max() / ref.abs().max())
+    err_naive = float((flat_naive - ref).abs().max() / ref.abs().max())
+    q.put((rank, err, err_naive, bool((own != corner).any())))
+    dist.destroy_process_group()
+
+
+def test_real_batch_split_world2_gloo_oracle():
+    """The second sharding level is exact: every rank takes half of a class's real batch, computes the parameter gradients of
+    sum(CE) / n_whole with the oracle -- instance norm is per cloud, the cross entropy a mean over clouds -- and one all-reduce(SUM) gives
+    the whole batch's gw_real (mnist_distill.py:344-350) to 1e-9, PROVIDED dense() places every half by the whole batch's minimum
+    corner (MEConv.py:251-254 takes the minimum over the batch): with a half's own corner the classifier-weight gradient lands on
+    shifted sites, which the test shows too."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_split_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    print("split real batch, all-reduced gw_real vs whole batch: rel err", [r[1] for r in res], "with the halves' own corners:", [r[2] for r in res])
+    assert all(r[1] < 1e-9 for r in res)
+    assert any(r[3] for r in res)              # a half whose own corner differs from the batch's exists in this test ...
+    assert all(r[2] > 1e-3 for r in res)       # ... and placing it by that corner is NOT the reference's result
