@@ -312,13 +312,15 @@ __global__ __launch_bounds__(CT) void k_cloud_count(const float4* __restrict__ c
 constexpr int GMIN_LDS_GROUPS = 1024;  // groups whose minimum corners k_cloud_scan folds in LDS (more: global atomics after a memset)
 __global__ void k_cloud_scan(const int* __restrict__ cnt, int B, int* __restrict__ seg /*[3][B+1]*/, int* __restrict__ counts /*[3]*/,
                              const int* __restrict__ group_cloud_off, int G, int* __restrict__ gro /*[3][G+1] or null*/,
-                             const int* __restrict__ cmin /*[3][B] or null*/, const int* __restrict__ cloud_group, int* __restrict__ gmin /*[G][3]*/) {
+                             const int* __restrict__ cmin /*[3][B] or null*/, const int* __restrict__ cloud_group, int* __restrict__ gmin /*[G][3]*/,
+                             const int* __restrict__ gmin_floor /*[G][3] or null*/) {
     __shared__ int s_w[16];
     __shared__ int s_carry;
     __shared__ int s_gmin[GMIN_LDS_GROUPS * 3];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (cmin) {  // gmin[g][a] = min over the clouds of group g (G <= GMIN_LDS_GROUPS, checked by the host)
-        for (int i = threadIdx.x; i < G * 3; i += 1024) s_gmin[i] = 0x7F7F7F7F;
+        // (a caller that holds only PART of a group's clouds brings the corner of the rest: dense() places by the whole group's minimum)
+        for (int i = threadIdx.x; i < G * 3; i += 1024) s_gmin[i] = gmin_floor ? gmin_floor[i] : 0x7F7F7F7F;
         __syncthreads();
         for (int i = threadIdx.x; i < 3 * B; i += 1024) {
             const int a = i / B, b = i - a * B;
@@ -512,7 +514,7 @@ __global__ __launch_bounds__(CT) void k_cloud_emit(const float4* __restrict__ co
 
 template <int NMAX>
 int launch_cloud_maps(const float4* coords, const int* pt_off, int B, const int* cloud_group, int* cnt, int* seg, int* counts, const CloudOut& o,
-                      int* gmin, int* err, const int* group_cloud_off, int G, int* gro, hipStream_t st) {
+                      int* gmin, int* err, const int* group_cloud_off, int G, int* gro, const int* gmin_floor, hipStream_t st) {
     int* cmin = (gmin && G <= GMIN_LDS_GROUPS) ? cnt + 3 * (int64_t)B : nullptr;
     const size_t smem = sizeof(CloudSmem<NMAX>);
     if (smem > 64 * 1024) {
@@ -520,7 +522,7 @@ int launch_cloud_maps(const float4* coords, const int* pt_off, int B, const int*
         DD3D_HIP(hipFuncSetAttribute((const void*)k_cloud_emit<NMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     }
     k_cloud_count<NMAX><<<dim3(B), CT, smem, st>>>(coords, pt_off, B, cloud_group, cnt, gmin, err, cmin, o.vox_at, o.E0 * o.E1 * o.E2);
-    k_cloud_scan<<<1, 1024, 0, st>>>(cnt, B, seg, counts, group_cloud_off, G, gro, cmin, cloud_group, gmin);
+    k_cloud_scan<<<1, 1024, 0, st>>>(cnt, B, seg, counts, group_cloud_off, G, gro, cmin, cloud_group, gmin, gmin_floor);
     k_cloud_emit<NMAX><<<dim3(B), CT, smem, st>>>(coords, pt_off, B, cloud_group, seg, o, err);
     DD3D_CHECK_LAUNCH();
     return 0;
@@ -537,8 +539,8 @@ DD3D_API int dd3d_cloud_maps(const float* coords, const int32_t* pt_off, int B, 
                              int E0, int E1, int E2, int32_t* counts /*[3]*/, int32_t* seg /*[3][B+1]*/, int32_t* C1, int32_t* C2, int32_t* C4,
                              int32_t* inv1, int32_t* uidx1, int32_t* vox_off, int32_t* vox_pts, int32_t* par2, int32_t* uidx2, int32_t* par4,
                              int32_t* uidx4, int32_t* nbr1, int32_t* nbr2, int32_t* kid2, int32_t* kid4, int64_t ld, int32_t* gmin, int32_t* site,
-                             int32_t* vox_at, const int32_t* group_cloud_off, int32_t* group_row_off /*[3][G+1]*/, int32_t* err_dev, void* ws,
-                             int64_t ws_bytes, void* stream) {
+                             int32_t* vox_at, const int32_t* group_cloud_off, int32_t* group_row_off /*[3][G+1]*/, const int32_t* gmin_floor /*[G][3] or null*/,
+                             int32_t* err_dev, void* ws, int64_t ws_bytes, void* stream) {
     if (B < 0 || max_points <= 0 || max_points > dd3d_cloud_maps_max_points() || bound < 0 || ld < bound || G <= 0 || !counts || !seg || !err_dev)
         return DD3D_EARG;
     if (bound >= (1ll << 31) / 32) return DD3D_ESIZE;
@@ -550,7 +552,10 @@ DD3D_API int dd3d_cloud_maps(const float* coords, const int32_t* pt_off, int B, 
     hipStream_t st = (hipStream_t)stream;
     // the dense table is cleared per cloud by k_cloud_count and the group corners are folded by k_cloud_scan: no memset nodes in a
     // captured step (only more groups than the scan holds in LDS, or no clouds at all, take the memset)
-    if (dense && (G > GMIN_LDS_GROUPS || B == 0)) DD3D_HIP(hipMemsetAsync(gmin, 0x7F, (size_t)G * 3 * 4, st));
+    if (dense && (G > GMIN_LDS_GROUPS || B == 0)) {
+        if (gmin_floor) DD3D_HIP(hipMemcpyAsync(gmin, gmin_floor, (size_t)G * 3 * 4, hipMemcpyDeviceToDevice, st));
+        else DD3D_HIP(hipMemsetAsync(gmin, 0x7F, (size_t)G * 3 * 4, st));
+    }
     if (B == 0) {
         DD3D_HIP(hipMemsetAsync(counts, 0, 12, st));
         DD3D_HIP(hipMemsetAsync(seg, 0, 12, st));
@@ -570,6 +575,6 @@ DD3D_API int dd3d_cloud_maps(const float* coords, const int32_t* pt_off, int B, 
     o.ld = ld; o.E0 = E0; o.E1 = E1; o.E2 = E2;
     int* cnt = (int*)ws;
     if (max_points <= 256)
-        return launch_cloud_maps<256>((const float4*)coords, pt_off, B, cloud_group, cnt, seg, counts, o, dense ? gmin : nullptr, err_dev, group_cloud_off, G, group_row_off, st);
-    return launch_cloud_maps<1024>((const float4*)coords, pt_off, B, cloud_group, cnt, seg, counts, o, dense ? gmin : nullptr, err_dev, group_cloud_off, G, group_row_off, st);
+        return launch_cloud_maps<256>((const float4*)coords, pt_off, B, cloud_group, cnt, seg, counts, o, dense ? gmin : nullptr, err_dev, group_cloud_off, G, group_row_off, gmin_floor, st);
+    return launch_cloud_maps<1024>((const float4*)coords, pt_off, B, cloud_group, cnt, seg, counts, o, dense ? gmin : nullptr, err_dev, group_cloud_off, G, group_row_off, gmin_floor, st);
 }

@@ -68,13 +68,16 @@ class _Pass:
     pass is the same kernels called on the first ``B_syn`` clouds with the prefix's row counts (``seg_off[B_syn]``, on the device)."""
 
     def __init__(self, net, coords, B, G, cloud_group, group_cloud_off, B_syn, N_syn, side, n_dev=None, static=False, pt_off=None, max_points=0,
-                 extent=None, side2=None, stash=None):
+                 extent=None, side2=None, stash=None, Gs=None, dl_scale=None, gmin_floor=None):
         """Phase 1 (no host sync): every coordinate map, enqueued on the current stream.
         ``static``: never read a size back -- every launch covers its bound and takes the true row count from the device
         (``n_dev`` = number of valid rows of ``coords``), so the pass can be captured into a HIP graph."""
         dev = coords.device
         self.dev, self.B, self.G, self.net = dev, B, G, net
-        self.B_syn, self.N_syn, self.Gs = B_syn, N_syn, G // 2
+        # Gs synthetic groups first, then the real ones (G - Gs of them: the same classes unless the real batches of further classes are
+        # shared with other ranks, FusedDistiller's second sharding level); dl_scale [B - B_syn, 1]: weight of every real cloud's logit
+        # gradient (a rank holding n_part of a class's n clouds contributes sum(CE) / n, not its own mean)
+        self.B_syn, self.N_syn, self.Gs, self.dl_scale = B_syn, N_syn, (G // 2 if Gs is None else Gs), dl_scale
         self.cloud_group, self.gco = cloud_group, group_cloud_off
         self.static, self.side, self.side2 = static, side, side2 if side2 is not None else side
         # dense() placement over `extent` sites per axis: the network's dense extent, or the (smaller) box the voxels can actually reach
@@ -82,10 +85,10 @@ class _Pass:
         if pt_off is not None and 0 < max_points <= int(L.lib.dd3d_cloud_maps_max_points()):
             # clouds small enough for LDS: the whole pyramid (+ dense placement) in three launches
             cm = CloudCoordinateManager(coords, pt_off, B, max_points, extent, cloud_group, G, group_cloud_off,
-                                        out=None if stash is None else {k: stash[k] for k in ("nbr1", "nbr2", "gro")})
+                                        out=None if stash is None else {k: stash[k] for k in ("nbr1", "nbr2", "gro")}, gmin_floor=gmin_floor)
         else:
-            if stash is not None:
-                raise ValueError("the deferred-loss mode needs the cloud-local map builder (clouds of at most 1024 points)")
+            if stash is not None or gmin_floor is not None:
+                raise ValueError("the deferred-loss mode and split real batches need the cloud-local map builder (clouds of at most 1024 points)")
             cm = CoordinateManager(coords, B, n_dev=n_dev)
         self.cm, self.stash = cm, stash
         self.N = cm.N
@@ -184,6 +187,8 @@ class _Pass:
         closs, self.ce = _empty((B,), dev), _empty((G,), dev)
         L.call("dd3d_softmax_ce", L.ptr(logits), L.ptr(labels), L.ptr(cloud_group), L.ptr(group_cloud_off), G, B, J, L.ptr(prob), L.ptr(dl),
                L.ptr(closs), L.ptr(self.ce), st)
+        if self.dl_scale is not None:   # every first-order gradient below is linear in dl
+            dl[self.B_syn:].mul_(self.dl_scale)
 
         # ---------------- first-order backward: one gradient list per group ----------------
         # The parameter gradients of the classifier and of the 128-channel convolution feed nothing but the matching loss, so they run
@@ -419,8 +424,17 @@ class FusedDistiller:
 
     def __init__(self, images_all, indices_class, network, ipc, num_classes=10, num_points=250, batch_size=256, dist_opt="modmse",
                  dist_lr=0.1, device=None, seed=0, image_syn=None, classes=None, momentum=0.5, graph=True, real_clouds=None,
-                 quantization_size=1.0, clamp_range=(0.0, 27.0), zero_first_axis=True, defer_loss=False):
-        """``real_clouds`` (optional, instead of ``images_all``): the real data as point clouds -- a float tensor [n, P, 3] or a list of
+                 quantization_size=1.0, clamp_range=(0.0, 27.0), zero_first_axis=True, defer_loss=False, real_classes=None, real_part=(0, 1),
+                 exchange=None):
+        """``real_classes`` / ``real_part`` / ``exchange``: the second sharding level.  This process computes the
+        real-batch gradients of ``real_classes`` (default: its own ``classes``; must contain them) over part ``real_part = (p, P)`` of
+        every sampled batch -- clouds p, p + P, ... of the SAME permutation every process of the group draws (same ``seed``) --
+        weighted n_part / n so that the parts add up to the whole batch's gw_real (instance norm is per cloud, the cross entropy a mean
+        over clouds, dense() is placed by the whole sample's minimum corner).  ``exchange(flat)``: sums the flat fp32 buffer of those
+        partial gradients over the processes that share the classes, in place (``sharding.all_reduce_in(group)``); called between
+        the first-order backward and the matching loss, outside graph capture (the step is then two graphs around it).  The synthetic
+        clouds, the loss, the second-order pass and the update stay with ``classes``.
+        ``real_clouds`` (optional, instead of ``images_all``): the real data as point clouds -- a float tensor [n, P, 3] or a list of
         [n_i, 3] tensors; coordinates = features = the points (what Mnist2Dreal does with pixels), coordinates divided by
         ``quantization_size`` (create_input_batch).  ``clamp_range`` / ``zero_first_axis``: the per-iteration clamp of the synthetic
         points (mnist_distill.py:311-317: [0, 27], depth := 0); ``clamp_range=None`` switches it off for 3-D clouds."""
@@ -446,6 +460,23 @@ class FusedDistiller:
         self.optimizer_img = _SgdState(self)
         self.lr, self.momentum, self.steps_done = dist_lr, momentum, 0
         G = self.G = len(self.classes)
+        self.real_classes = list(self.classes) if real_classes is None else list(real_classes)
+        self.real_part = (int(real_part[0]), int(real_part[1]))
+        if not (0 <= self.real_part[0] < self.real_part[1]) or any(c not in self.real_classes for c in self.classes):
+            raise ValueError("real_part = (p, P) with 0 <= p < P, and real_classes must contain classes")
+        self.exchange = exchange
+        self.split = self.real_part[1] > 1 or self.real_classes != self.classes
+        if self.split and exchange is None:
+            raise ValueError("a split real batch needs exchange(flat) to sum the partial gradient lists")
+        self.Gr = len(self.real_classes)
+        self.own_idx = torch.tensor([self.real_classes.index(c) for c in self.classes], device=dev, dtype=torch.long)
+        self._sizes_full = [min(batch_size, len(self.indices_class[c])) for c in self.real_classes]
+        self._sizes = [len(range(self.real_part[0], n, self.real_part[1])) for n in self._sizes_full]
+        self.dl_scale = None
+        if self.split:   # weight of every real cloud's logit gradient: n_part / n_whole of its class
+            w = [a / b if b else 0.0 for a, b in zip(self._sizes, self._sizes_full)]
+            self.dl_scale = torch.tensor(np.repeat(w, self._sizes), device=dev, dtype=_F32)[:, None].contiguous()
+        self._corners = self._floor_np = None
         cls = torch.tensor(self.classes, device=dev)
         # rows of image_syn owned by this process, class-major
         self.syn_rows = (cls[:, None] * ipc + torch.arange(ipc, device=dev)[None, :]).reshape(-1)
@@ -471,7 +502,7 @@ class FusedDistiller:
         # their operands in a stash (two sets, alternating) and the NEXT step's graph computes them on side streams next to its own
         # map building and first layer, where the matrix cores are idle.  ``outer_step`` then returns the complete loss of the PREVIOUS
         # step (zero on the first one); ``flush()`` completes and returns the last step's.  Same kernels, same bits, one step later.
-        self.defer = bool(defer_loss) and self.use_graph and dist_opt in ("ours", "modmse", "mse")
+        self.defer = bool(defer_loss) and self.use_graph and dist_opt in ("ours", "modmse", "mse") and not self.split
         self._stash, self._pending, self._graphs = None, None, [None, None]
         self._graph = self._static = None
         self._graph_stamp, self._needs_eager, self._last_loss = None, False, None
@@ -559,17 +590,46 @@ class FusedDistiller:
         return self._pool
 
     # ------------------------------------------------------------------ eager-mode real batch (host-sized tensors)
+    def _corner_table(self):
+        """[n_pool, 3] int32 (host): minimum stride-4 voxel corner of every cloud of the pool, as dd3d_cloud_maps computes it from
+        coordinates = points / quantization_size (fp32).  One pass over the pool, once."""
+        if self._corners is None:
+            xyz, off = self._point_pool()
+            n, dev = int(off.numel()) - 1, self.device
+            cnt = (off[1:] - off[:-1]).long()
+            seg = torch.repeat_interleave(torch.arange(n, device=dev), cnt)
+            vox = torch.floor(xyz[:int(off[-1])] / self.quant)
+            mn = torch.full((n, 3), float("inf"), device=dev).scatter_reduce_(0, seg[:, None].expand(-1, 3), vox, "amin")
+            c = torch.floor(mn / 4) * 4
+            c[torch.isinf(c)] = float(0x7F7F7F7F)   # a cloud without points has no corner
+            self._corners = c.to(torch.int64).to(torch.int32).cpu().numpy()
+        return self._corners
+
     def _draw(self):
-        """mnist_distill.py:200-203 for every owned class: np.random.permutation(indices_class[c])[:batch_size]."""
-        return np.concatenate([self.rng.permutation(self.indices_class[c])[:self.batch_size] for c in self.classes])
+        """mnist_distill.py:200-203 for every class whose real batch this process works on: np.random.permutation(indices_class[c])
+        [:batch_size], and of it the clouds p, p + P, ... (``real_part``; all of it by default).  With a split batch also the minimum
+        corner of the WHOLE sample per class -> self._floor_np [G + Gr, 3] (no floor for the synthetic groups)."""
+        p, P = self.real_part
+        ids, floor = [], [np.full((self.G, 3), 0x7F7F7F7F, dtype=np.int32)]
+        for c in self.real_classes:
+            full = self.rng.permutation(self.indices_class[c])[:self.batch_size]
+            ids.append(full[p::P])
+            if self.split:
+                floor.append(self._corner_table()[full].min(0, keepdims=True) if len(full) else np.full((1, 3), 0x7F7F7F7F, dtype=np.int32))
+        self._floor_np = np.concatenate(floor).astype(np.int32) if self.split else None
+        return np.concatenate(ids)
 
     def sample_real(self):
         """mnist_distill.py:200-208 for every owned class at once: one gather + one nonzero."""
         idx = self._draw()
-        sizes = [min(self.batch_size, len(self.indices_class[c])) for c in self.classes]
+        sizes = self._sizes
         if self.images_all is None:
-            return self.real_batch_from_pool(idx, sizes)
-        return self.real_batch_from_images(self.images_all[torch.as_tensor(idx, device=self.device)], sizes)
+            b = self.real_batch_from_pool(idx, sizes)
+        else:
+            b = self.real_batch_from_images(self.images_all[torch.as_tensor(idx, device=self.device)], sizes)
+        if self.split:
+            b["gmin_floor"] = torch.from_numpy(self._floor_np).to(self.device)
+        return b
 
     def real_batch_from_pool(self, idx, sizes):
         """The collated batch of the sampled clouds ``idx`` (coordinates = points / quantization_size, features = points)."""
@@ -582,17 +642,17 @@ class FusedDistiller:
         rows = start[b] + (torch.arange(int(pt[-1]), device=dev) - pt[b])
         p = xyz[rows]
         return {"coordinates": torch.cat([b[:, None].to(_F32), p / self.quant], 1), "features": p.clone(), "num_clouds": int(ids.numel()),
-                "labels": torch.tensor(np.repeat(self.classes, sizes), device=dev), "pt_off": pt.to(_I32),
-                "cloud_group": torch.tensor(np.repeat(np.arange(self.G), sizes), device=dev, dtype=_I32),
+                "labels": torch.tensor(np.repeat(self.real_classes, sizes), device=dev), "pt_off": pt.to(_I32),
+                "cloud_group": torch.tensor(np.repeat(np.arange(self.Gr), sizes), device=dev, dtype=_I32),
                 "group_cloud_off": torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), device=dev, dtype=_I32), "max_per": int(max(sizes))}
 
     def real_batch_from_images(self, images, sizes):
         dev = self.device
-        labels = torch.tensor(np.repeat(self.classes, sizes), device=dev)
+        labels = torch.tensor(np.repeat(self.real_classes, sizes), device=dev)
         b = batch_from_images(images, labels, self.num_points)
         if self.quant != 1.0:
             b["coordinates"][:, 1:] /= self.quant
-        b["cloud_group"] = torch.tensor(np.repeat(np.arange(self.G), sizes), device=dev, dtype=_I32)
+        b["cloud_group"] = torch.tensor(np.repeat(np.arange(self.Gr), sizes), device=dev, dtype=_I32)
         b["group_cloud_off"] = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), device=dev, dtype=_I32)
         b["max_per"] = int(max(sizes))
         return b
@@ -605,9 +665,9 @@ class FusedDistiller:
         st.pool_xyz, st.pool_off = self._point_pool()
         st.n_pool = int(st.pool_off.numel()) - 1
         counts = (st.pool_off[1:] - st.pool_off[:-1]).cpu().numpy()
-        sizes = [min(self.batch_size, len(self.indices_class[c])) for c in self.classes]
+        sizes = self._sizes
         # tight bound on the points of one sampled batch: the `size` largest clouds of every class
-        bound = sum(int(np.sort(counts[self.indices_class[c]])[::-1][:n].sum()) for c, n in zip(self.classes, sizes))
+        bound = sum(int(np.sort(counts[self.indices_class[c]])[::-1][:n].sum()) for c, n in zip(self.real_classes, sizes))
         st.bound = max(256, (bound + 255) // 256 * 256)
         st.sizes, st.B = sizes, int(sum(sizes))
         # merged batch: the synthetic clouds first (fixed sizes), then the sampled real clouds
@@ -621,8 +681,8 @@ class FusedDistiller:
         st.pt_off[:Bs + 1] = self.syn_pt_off
         st.n = torch.zeros(1, dtype=_I32, device=dev)
         st.err = torch.zeros(1, dtype=_I32, device=dev)
-        rl = torch.tensor(np.repeat(self.classes, sizes), device=dev, dtype=_I32)
-        rg = torch.tensor(np.repeat(np.arange(G), sizes), device=dev, dtype=_I32)
+        rl = torch.tensor(np.repeat(self.real_classes, sizes), device=dev, dtype=_I32)
+        rg = torch.tensor(np.repeat(np.arange(self.Gr), sizes), device=dev, dtype=_I32)
         rgco = torch.tensor(np.cumsum(sizes), device=dev, dtype=_I32)
         st.labels = torch.cat([self.syn_labels, rl])
         st.cloud_group = torch.cat([self.syn_group, rg + G])
@@ -634,6 +694,8 @@ class FusedDistiller:
                             "nbr1": _empty((27, bt), dev, _I32), "nbr2": _empty((27, bt), dev, _I32), "gro": _empty((3, G2 + 1), dev, _I32),
                             "g_b1": _empty((G2, 128), dev), "g_b5": _empty((G2, 128), dev), "loss_a": torch.zeros(G, device=dev),
                             "loss": torch.zeros(G, device=dev), "ld": bt, "parity": i} for i in range(2)]
+        st.gmin_floor = torch.full((G + self.Gr, 3), 0x7F7F7F7F, dtype=_I32, device=dev) if self.split else None
+        st.pin_floor = [torch.empty((G + self.Gr, 3), dtype=_I32).pin_memory() for _ in range(4)] if self.split else None
         st.pin = [torch.empty(max(st.B, 1), dtype=_I32).pin_memory() for _ in range(4)]
         st.pin_ev = [torch.cuda.Event() for _ in range(4)]
         st.pin_i = 0
@@ -647,6 +709,9 @@ class FusedDistiller:
         st.pin_ev[i].synchronize()                # the upload that last used this staging buffer has finished
         st.pin[i].numpy()[:st.B] = self._draw()
         st.ids.copy_(st.pin[i], non_blocking=True)
+        if self.split:
+            st.pin_floor[i].numpy()[:] = self._floor_np
+            st.gmin_floor.copy_(st.pin_floor[i], non_blocking=True)
         st.pin_ev[i].record()
 
     # ------------------------------------------------------------------ the step
@@ -663,7 +728,7 @@ class FusedDistiller:
                 "labels": torch.cat([self.syn_labels, rb["labels"].to(_I32)]), "num_clouds": Bs + int(rb["num_clouds"]),
                 "cloud_group": torch.cat([self.syn_group, rb["cloud_group"] + G]),
                 "group_cloud_off": torch.cat([self.syn_gco, rb["group_cloud_off"][1:] + Bs]),
-                "pt_off": torch.cat([self.syn_pt_off, pt[1:] + Ns]), "n_dev": None, "extent": rb.get("extent")}
+                "pt_off": torch.cat([self.syn_pt_off, pt[1:] + Ns]), "n_dev": None, "extent": rb.get("extent"), "gmin_floor": rb.get("gmin_floor")}
 
     def _run_deferred(self, stash):
         """The loss-value-only work a deferred step left behind: both convolutions' kernel gradients over the stashed operands (the
@@ -695,17 +760,42 @@ class FusedDistiller:
         main.wait_stream(self.stream_defer)
         return self._pending["loss"].sum()
 
+    def _do_exchange(self, flat):
+        self.exchange(flat)
+
+    @staticmethod
+    def _finish(gen):
+        """Run a step generator to its end (it must not yield again) and return its value."""
+        try:
+            next(gen)
+        except StopIteration as e:
+            return e.value
+        raise RuntimeError("the step yielded twice")
+
     def _compute(self, mb, static, stash=None):
+        """_compute_gen with the exchange of a split real batch (if any) done in line."""
+        gen = self._compute_gen(mb, static, stash)
+        try:
+            flat = next(gen)
+        except StopIteration as e:
+            return e.value
+        self._do_exchange(flat)
+        return self._finish(gen)
+
+    def _compute_gen(self, mb, static, stash=None):
         """Everything after the merged batch ``mb`` exists: one forward / first-order backward over synthetic + real clouds, the matching
-        loss, the second-order backward into the synthetic points, the SGD update.  ``stash``: deferred-loss mode (see __init__)."""
+        loss, the second-order backward into the synthetic points, the SGD update.  ``stash``: deferred-loss mode (see __init__).
+        A generator: with a split real batch it yields ONCE, the flat buffer of partial real gradients that the caller sums over the
+        ranks sharing the classes (between two graph captures, or in line); otherwise it runs through."""
         dev, G, ipc, npts = self.device, self.G, self.ipc, self.num_points
         # cached layouts of the frozen weights are (re)built here if a weight changed
         net = self.network
         extent = mb.get("extent") or self.site_extent()
         compact_site_major(net.classifier.weight, 128, net.dense_extent, extent)
         transposed_kernel(net.features[4].kernel)
-        p = _Pass(net, mb["coordinates"], int(mb["num_clouds"]), 2 * G, mb["cloud_group"], mb["group_cloud_off"], G * ipc, G * ipc * npts,
-                  self.stream_side, mb.get("n_dev"), static, mb.get("pt_off"), npts, extent, self.stream_side2, stash)
+        p = _Pass(net, mb["coordinates"], int(mb["num_clouds"]), G + self.Gr, mb["cloud_group"], mb["group_cloud_off"], G * ipc, G * ipc * npts,
+                  self.stream_side, mb.get("n_dev"), static, mb.get("pt_off"), npts, extent, self.stream_side2, stash, Gs=G,
+                  dl_scale=self.dl_scale, gmin_floor=mb.get("gmin_floor"))
         p.run(mb["features"], mb["labels"], defer=stash is not None)
         gw_syn, gw_real = [None if t is None else t[:G] for t in p.gw], [None if t is None else t[G:] for t in p.gw]
         # Only these entries of gw_syn depend on the synthetic points (SURVEY.md section 3.2): IN weights, classifier weight and bias.  For the
@@ -715,7 +805,22 @@ class FusedDistiller:
         # layers together and keeps the joint launch.
         main, side = torch.cuda.current_stream(dev), self.stream_side
         diff, const = [1, 4, 6, 7], [0, 2, 3, 5]
-        if stash is not None:
+        if self.split:
+            # second sharding level: this rank's PARTIAL real gradients (already weighted n_part / n) are summed over the ranks that share
+            # the classes; every stream joins first (a graph capture may end here)
+            main.wait_stream(side)
+            main.wait_stream(p.side2)
+            flat = torch.cat([t.reshape(-1) for t in gw_real])
+            yield flat
+            full, off = [], 0
+            for t in gw_real:
+                full.append(flat[off:off + t.numel()].view(t.shape))
+                off += t.numel()
+            gw_real = [t.index_select(0, self.own_idx) for t in full] if self.real_classes != self.classes else full
+            need = [i in diff for i in range(8)]
+            loss_g, d = grouped_match_loss(gw_syn, gw_real, self.dist_opt, G, need)
+            dfeats = p.backward_to_points(d[1], d[4], d[6], d[7], ipc)
+        elif stash is not None:
             main.wait_event(p.ev_cls)
             loss_a, d4 = grouped_match_loss([gw_syn[i] for i in diff], [gw_real[i] for i in diff], self.dist_opt, G, [True] * 4, loss_out=stash["loss_a"])
             dfeats = p.backward_to_points(d4[0], d4[1], d4[2], d4[3], ipc)
@@ -757,8 +862,19 @@ class FusedDistiller:
         return loss_g.sum()
 
     def _static_body(self, parity=0):
+        """_static_body_gen with the exchange of a split real batch (if any) done in line (the eager first step)."""
+        gen = self._static_body_gen(parity)
+        try:
+            flat = next(gen)
+        except StopIteration as e:
+            return e.value
+        self._do_exchange(flat)
+        return self._finish(gen)
+
+    def _static_body_gen(self, parity=0):
         """clamp + on-device batch assembly + the step, all on fixed addresses with device-side sizes (what the graph captures).
-        Deferred-loss mode: the previous step's pending loss-value work first, on the side streams, next to this step's own kernels."""
+        Deferred-loss mode: the previous step's pending loss-value work first, on the side streams, next to this step's own kernels.
+        A generator like _compute_gen (yields the exchange buffer of a split real batch)."""
         st = self._static
         stash = self._stash[parity] if self.defer else None
         Bs, Ns = self.G * self.ipc, self.G * self.ipc * self.num_points
@@ -776,9 +892,9 @@ class FusedDistiller:
         L.call("dd3d_gather_clouds", L.ptr(st.pool_xyz), L.ptr(st.pool_off), st.n_pool, L.ptr(st.ids), st.B, self.num_points, st.bound_total,
                Bs, Ns, self.quant, L.ptr(st.coords), L.ptr(st.feats), L.ptr(st.pt_off), L.ptr(st.n), L.ptr(st.err), L.stream())
         mb = {"coordinates": st.coords, "features": st.feats, "labels": st.labels, "num_clouds": Bs + st.B, "cloud_group": st.cloud_group,
-              "group_cloud_off": st.gco, "n_dev": st.n, "pt_off": st.pt_off}
+              "group_cloud_off": st.gco, "n_dev": st.n, "pt_off": st.pt_off, "gmin_floor": st.gmin_floor}
         with L.ws_scope(self._scope + ("p%d" % parity if self.defer else "")):
-            out = self._compute(mb, True, stash)
+            out = yield from self._compute_gen(mb, True, stash)
         if self.defer:
             main = torch.cuda.current_stream(self.device)
             main.wait_stream(self.stream_defer)   # (also what lets a capture end: every forked stream rejoins)
@@ -815,7 +931,21 @@ class FusedDistiller:
                 loss = self._static_body(parity)
                 self._needs_eager = False
             else:
-                if self._graphs[parity] is None:
+                if self._graphs[parity] is None and self.split:
+                    # split real batch: the exchange (an RCCL all-reduce) sits BETWEEN two captures, both in one memory pool
+                    g, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        gen = self._static_body_gen(parity)
+                        flat = next(gen)
+                    with torch.cuda.graph(g2, pool=g.pool(), capture_error_mode="thread_local"):
+                        gl = self._finish(gen)
+                    self._graphs[parity] = (g, gl, self.last, self._pending, flat, g2)
+                    self._graph_stamp = self._param_stamp()
+                    self._graph, loss = g, gl
+                    g.replay()
+                    self._do_exchange(flat)
+                    g2.replay()
+                elif self._graphs[parity] is None:
                     g = torch.cuda.CUDAGraph()
                     # thread_local: only this thread's calls are checked during capture (an RCCL watchdog thread polling its events
                     # must not invalidate it)
@@ -824,14 +954,22 @@ class FusedDistiller:
                     # deferred mode: the graph of parity p runs the pending work of the step before it (stash 1 - p) and leaves its own in stash p
                     self._graphs[parity] = (g, gl, self.last, self._pending)
                     self._graph_stamp = self._param_stamp()
-                self._graph, loss, self.last, self._pending = self._graphs[parity]
-                self._graph.replay()
+                    self._graph, loss = g, gl
+                    self._graph.replay()
+                else:
+                    self._graph, loss, self.last, self._pending = self._graphs[parity][:4]
+                    self._graph.replay()
+                    if self.split:
+                        self._do_exchange(self._graphs[parity][4])
+                        self._graphs[parity][5].replay()
             self._last_loss = loss
             self.steps_done += 1
             return loss
         self.clamp()
         main = torch.cuda.current_stream(self.device)
         if real_batch is not None:
+            if self.split:
+                raise ValueError("a split real batch is sampled inside the step (every rank of the group draws the same permutation)")
             rb = dict(real_batch)
             rb["extent"] = self.site_extent(real_batch)
         elif self._prefetched is not None:

@@ -48,3 +48,37 @@ def gather_synthetic(image_syn: torch.Tensor, ipc: int, num_classes: int) -> tor
         out[c * ipc:(c + 1) * ipc] = image_syn[c * ipc:(c + 1) * ipc]
     dist.all_reduce(out, op=dist.ReduceOp.SUM)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Second level: the real batch of a class split over ranks
+# ---------------------------------------------------------------------------------------------------------------------
+def split_layout(num_classes: int, rank: int, world: int, real_parts: int = 0):
+    """world = class_shards x real_parts.  Rank r = (shard r // P, part r % P): it computes the real-batch gradients of ALL classes of its
+    shard (class c belongs to shard ``c mod class_shards``) over part ``r % P`` of every sampled batch, and owns the synthetic clouds,
+    the matching loss and the update of every P-th class of the shard.  ``real_parts = 0``: the smallest P for which the classes divide
+    evenly over the shards (10 classes: 8 ranks = 2 shards x 4 parts, 4 ranks = 2 x 2, 2 ranks = 2 x 1 -- every rank then holds the
+    same number of real clouds, where class sharding alone leaves 2 classes on two of 8 ranks and 1 on the others).
+    Returns dict(classes, real_classes, real_part, group_ranks); the FusedDistiller arguments of the same names."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    if real_parts <= 0:
+        shards = max(d for d in range(1, world + 1) if world % d == 0 and num_classes % d == 0)
+        real_parts = world // shards
+    if world % real_parts:
+        raise ValueError("real_parts must divide the world size")
+    shards = world // real_parts
+    cs, rp = rank // real_parts, rank % real_parts
+    mine = [c for c in range(num_classes) if c % shards == cs]
+    owned = [c for j, c in enumerate(mine) if j % real_parts == rp]
+    if not owned:
+        raise ValueError(f"{len(mine)} classes per shard cannot give each of {real_parts} ranks a synthetic class to own")
+    return {"classes": owned, "real_classes": mine, "real_part": (rp, real_parts), "group_ranks": [cs * real_parts + i for i in range(real_parts)]}
+
+
+def all_reduce_in(group):
+    """exchange(flat) for FusedDistiller: sum the flat buffer of partial real-batch gradients over the ranks of ``group`` (the ranks that
+    share a class shard), in place -- RCCL over xGMI on the GPUs, gloo in the tests.  Called outside graph capture."""
+    def exchange(flat: torch.Tensor):
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return exchange

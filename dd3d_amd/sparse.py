@@ -206,8 +206,10 @@ class CloudCoordinateManager(CoordinateManager):
 
     def __init__(self, coords: torch.Tensor, pt_off: torch.Tensor, num_clouds: int, max_points: int, dense_extent=None,
                  cloud_group: Optional[torch.Tensor] = None, num_groups: int = 1, group_cloud_off: Optional[torch.Tensor] = None,
-                 out: Optional[dict] = None):
-        """``out`` (optional): caller-owned buffers for the outputs that outlive the step in the deferred-loss mode of the fused step --
+                 out: Optional[dict] = None, gmin_floor: Optional[torch.Tensor] = None):
+        """``gmin_floor`` (optional, int32 [num_groups, 3]): the minimum stride-4 corner of the clouds of every group that are NOT in this
+        batch (0x7F7F7F7F = none): dense() then places by the minimum over the whole group, as if all its clouds were here.
+        ``out`` (optional): caller-owned buffers for the outputs that outlive the step in the deferred-loss mode of the fused step --
         ``nbr1`` / ``nbr2`` int32 [27, >= N] and ``gro`` int32 [3, num_groups + 1]; their leading dimension is the table stride."""
         if coords.dim() != 2 or coords.shape[1] != 4:
             raise ValueError("coordinates must be [N,4] = (batch, c1, c2, c3)")
@@ -245,8 +247,8 @@ class CloudCoordinateManager(CoordinateManager):
         L.call("dd3d_cloud_maps", L.ptr(coords), L.ptr(pt_off), B, int(max_points), self.N, L.ptr(cloud_group), int(num_groups), E[0], E[1], E[2],
                L.ptr(self.counts), L.ptr(seg), L.ptr(C[0]), L.ptr(C[1]), L.ptr(C[2]), L.ptr(inv1), L.ptr(uidx1), L.ptr(self.vox_off),
                L.ptr(self.vox_pts), L.ptr(par2), L.ptr(uidx2), L.ptr(par4), L.ptr(uidx4), L.ptr(nbr1), L.ptr(nbr2), L.ptr(kid2), L.ptr(kid4), bound,
-               L.ptr(gmin), L.ptr(site), L.ptr(vox_at), L.ptr(group_cloud_off), L.ptr(self.group_row_off), L.ptr(self.err), L.ptr(ws), ws.numel(),
-               L.stream())
+               L.ptr(gmin), L.ptr(site), L.ptr(vox_at), L.ptr(group_cloud_off), L.ptr(self.group_row_off), L.ptr(gmin_floor), L.ptr(self.err), L.ptr(ws),
+               ws.numel(), L.stream())
         for slot, (stride, inv, uidx) in enumerate(((1, inv1, uidx1), (2, par2, uidx2), (4, par4, uidx4))):
             lv = _Level()
             lv.stride, lv.bound, lv.slot, lv.cap, lv.table = stride, self.N, slot, 0, None

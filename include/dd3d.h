@@ -94,7 +94,9 @@ int dd3d_gather_clouds(const float* pool_xyz, const int32_t* pool_off, int n_poo
  * uidx1, vox_off, vox_pts; par2/par4 (row at the coarser stride) and uidx2/uidx4 (first finer row); nbr1/nbr2 [27][ld] k=3 kernel
  * maps at strides 1 and 2; kid2/kid4 [8][ld] k=2 stride-2 pooling maps; optional dense placement of stride 4 (gmin[G,3], site,
  * vox_at[E0*E1*E2][B]; pass site = NULL to skip); optional group_row_off[3][G+1] = first row of every group of clouds at the three
- * strides, from group_cloud_off[G+1] (nullable pair).  *err_dev |= 1 batch column of a point != its cloud, |= 2 voxel outside the
+ * strides, from group_cloud_off[G+1] (nullable pair); optional gmin_floor[G,3]: an upper bound of every group's minimum corner -- the
+ * corner of the clouds of the group that are NOT in this call (a rank that holds part of a class's real batch: dense() places by the
+ * minimum over the whole batch, MEConv.py:251-254).  *err_dev |= 1 batch column of a point != its cloud, |= 2 voxel outside the
  * dense extent, |= 8 a cloud has more than max_points points.
  * replaces: x.sparse(), the coordinate maps of both MinkowskiConvolution and both MinkowskiMaxPooling layers and the index math of
  * SparseTensor.dense(), models/MEConv.py:247,224,227,250-254 */
@@ -104,7 +106,7 @@ int dd3d_cloud_maps(const float* coords, const int32_t* pt_off, int B, int max_p
                     int E1, int E2, int32_t* counts, int32_t* seg, int32_t* C1, int32_t* C2, int32_t* C4, int32_t* inv1, int32_t* uidx1,
                     int32_t* vox_off, int32_t* vox_pts, int32_t* par2, int32_t* uidx2, int32_t* par4, int32_t* uidx4, int32_t* nbr1, int32_t* nbr2,
                     int32_t* kid2, int32_t* kid4, int64_t ld, int32_t* gmin, int32_t* site, int32_t* vox_at, const int32_t* group_cloud_off,
-                    int32_t* group_row_off, int32_t* err_dev, void* ws, int64_t ws_bytes, void* stream);
+                    int32_t* group_row_off, const int32_t* gmin_floor, int32_t* err_dev, void* ws, int64_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------------
  * (2) sparse convolution, gather-GEMM with atomic-free output (fp32 MFMA for Cin = 128)

@@ -412,3 +412,52 @@ def test_deferred_loss_mode_is_the_same_step_one_step_later(metric):
     assert fd2.flush().item() == prev
     fd.check()
     assert all(g is not None for g in fd._graphs)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_split_real_batch_parts_add_up_to_the_whole_step(graph):
+    """Second sharding level on one GPU: two distillers take part 0 and part 1 of every class's sampled real batch (same seed, so the
+    same permutations), weighted n_part / n and placed by the whole sample's minimum corner; part 1's flat buffer of partial real
+    gradients is handed to part 0 through the ``exchange`` hook -- what an all-reduce over the two ranks leaves on each.  Part 0's step
+    (loss, per-class losses, xyz gradient, updated points, gw_real) then equals the unsplit distiller's to fp32 rounding (the sums over
+    clouds are associated differently), over the eager first step, the two-graph capture and a replay.  Also with the synthetic side
+    owned for a SUBSET of the classes whose real batches are shared (helper ranks)."""
+    from dd3d_amd.fused_step import FusedDistiller
+    from dd3d_amd.synthetic import mnist3d_like
+    images, _, idx = mnist3d_like(4, 30, seed=5)
+    images[idx[2][:30], :, :12, :] = 0      # class 2 lives in the lower half of the grid: its minimum corner is not the origin ...
+    images[idx[2][7], :, 5, 3] = 1          # ... except for ONE cloud, which only one part of a split batch holds
+    syn = init_synthetic(4, 3, 250, seed=2)
+    kw = dict(ipc=3, num_classes=4, batch_size=24, device=DEV, seed=11, image_syn=syn, dist_opt="ours", graph=graph)
+    whole = FusedDistiller(images, idx, _net(), **kw)
+    box = {}
+    p1 = FusedDistiller(images, idx, _net(), real_part=(1, 2), exchange=lambda flat: box.__setitem__("p1", flat.clone()), **kw)
+    p0 = FusedDistiller(images, idx, _net(), real_part=(0, 2), exchange=lambda flat: flat.add_(box["p1"]), **kw)
+    # helper layout: this rank owns the synthetic clouds of classes 1 and 3 only, but works on the real batches of all four
+    h1 = FusedDistiller(images, idx, _net(), real_part=(1, 2), real_classes=[0, 1, 2, 3], classes=[1, 3],
+                        exchange=lambda flat: box.__setitem__("h1", flat.clone()), **kw)
+    h0 = FusedDistiller(images, idx, _net(), real_part=(0, 2), real_classes=[0, 1, 2, 3], classes=[1, 3],
+                        exchange=lambda flat: flat.add_(box["h1"]), **kw)
+    rows = torch.tensor([c * 3 + j for c in (1, 3) for j in range(3)], device=DEV)   # the synthetic clouds of classes 1 and 3
+    for step in range(3):
+        lw = whole.outer_step()
+        p1.image_syn.copy_(p0.image_syn)      # part 1 never sees the summed gradients in this test: keep its points with part 0's
+        p1.momentum_buf.copy_(p0.momentum_buf)
+        p1.outer_step()
+        l0 = p0.outer_step()
+        assert rel_err(l0.reshape(1), lw.reshape(1)) < 1e-5, (step, l0.item(), lw.item())
+        assert rel_err(p0.last["per_class"], whole.last["per_class"]) < 1e-5
+        assert rel_err(p0.last["grad"], whole.last["grad"]) < 2e-5
+        assert rel_err(p0.image_syn, whole.image_syn) < 1e-6
+        for i in range(8):
+            assert rel_err(p0.last["gw_real"][i].reshape(-1), whole.last["gw_real"][i].reshape(-1)) < 1e-5, i
+        h1.image_syn.copy_(h0.image_syn)
+        h1.momentum_buf.copy_(h0.momentum_buf)
+        h1.outer_step()
+        h0.outer_step()
+        assert rel_err(h0.last["per_class"], whole.last["per_class"][[1, 3]]) < 1e-5
+        assert rel_err(h0.last["grad"][rows], whole.last["grad"][rows]) < 2e-5 and rel_err(h0.image_syn[rows], whole.image_syn[rows]) < 1e-6
+    for d in (whole, p0, p1, h0, h1):
+        d.check()
+    if graph:
+        assert p0._graph is not None and len(p0._graphs[0]) == 6     # two graphs around the exchange

@@ -133,3 +133,19 @@ def test_real_batch_split_world2_gloo_oracle():
     assert all(r[1] < 1e-9 for r in res)
     assert any(r[3] for r in res)              # a half whose own corner differs from the batch's exists in this test ...
     assert all(r[2] > 1e-3 for r in res)       # ... and placing it by that corner is NOT the reference's result
+
+
+def test_split_layout_covers_every_class_once():
+    from dd3d_amd.sharding import split_layout
+    for world, parts in ((1, 0), (2, 0), (4, 0), (8, 0), (4, 4), (2, 2)):
+        lay = [split_layout(10, r, world, parts) for r in range(world)]
+        assert sorted(c for l in lay for c in l["classes"]) == list(range(10))            # every class has exactly one synthetic owner
+        for l in lay:
+            P = l["real_part"][1]
+            assert set(l["classes"]) <= set(l["real_classes"]) and len(l["group_ranks"]) == P
+            group = [lay[r] for r in l["group_ranks"]]
+            assert all(g["real_classes"] == l["real_classes"] for g in group)              # the group shares the shard's classes ...
+            assert sorted(g["real_part"][0] for g in group) == list(range(P))             # ... and covers every part of their batches
+    assert split_layout(10, 0, 8)["real_part"] == (0, 4) and len(split_layout(10, 5, 8)["real_classes"]) == 5
+    with pytest.raises(ValueError):
+        split_layout(3, 3, 4, 4)         # three classes in one shard: the fourth rank would own no synthetic class
