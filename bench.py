@@ -62,6 +62,9 @@ def main():
                          "cfg4 = 40 classes x 256 real ellipsoid-shell clouds x 1024 pts, voxel 0.05, ipc 10 (record runs, not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--emulate-shard", default="", help="R/W: time rank R's share of a W-rank job on this one GPU (no process group)")
+    ap.add_argument("--real-split", default="off", help="second sharding level (graph / fused path): 'off' = classes only; 'auto' or P = the real batch "
+                                                        "of every class of a shard split over P ranks, partial gradients all-reduced in the group "
+                                                        "(sharding.split_layout).  With --emulate-shard the exchange is left out (compute share only)")
     ap.add_argument("--defer-loss", action="store_true", help="graph path: compute each step's loss VALUE next to the following step (measured slower: DESIGN.md section 3)")
     ap.add_argument("--path", default="graph", choices=["graph", "fused", "dropin"],
                     help="graph: class-batched step captured into one HIP graph (default); fused: the same step enqueued eagerly; "
@@ -89,7 +92,7 @@ def main():
     from dd3d_amd import ops as _ops
 
     torch.manual_seed(0)
-    from dd3d_amd.sharding import max_over_ranks, owned_classes, reduce_loss
+    from dd3d_amd.sharding import all_reduce_in, max_over_ranks, owned_classes, reduce_loss, split_layout
     n_classes, n_points, extra = NUM_CLASSES, NUM_POINTS, {}
     if args.config == "cfg3":
         args.ipc = 50
@@ -109,15 +112,32 @@ def main():
         net = MEConvExp(in_channel=3, out_channel=10)
         syn = init_synthetic(NUM_CLASSES, args.ipc, NUM_POINTS, seed=0)
     my_classes = owned_classes(n_classes, rank, world)
+    er, ew = rank, world
     if args.emulate_shard:
         er, ew = (int(x) for x in args.emulate_shard.split("/"))
         my_classes = owned_classes(n_classes, er, ew)
+    split_kw = {}
+    if args.real_split != "off" and args.path != "dropin":
+        lay = split_layout(n_classes, er, ew, 0 if args.real_split == "auto" else int(args.real_split))
+        my_classes = lay["classes"]
+        if lay["real_part"][1] > 1:
+            if args.emulate_shard:
+                exchange = lambda flat: None       # the compute share of one rank; the all-reduce is not emulated
+            else:
+                groups = {}                        # every rank creates every group, in the same order
+                for r in range(world):
+                    gr = tuple(split_layout(n_classes, r, world, lay["real_part"][1])["group_ranks"])
+                    if gr not in groups:
+                        groups[gr] = torch.distributed.new_group(list(gr))
+                exchange = all_reduce_in(groups[tuple(lay["group_ranks"])])
+            split_kw = dict(real_classes=lay["real_classes"], real_part=lay["real_part"], exchange=exchange)
     kw = dict(ipc=args.ipc, num_classes=n_classes, num_points=n_points, batch_size=REAL_PER_CLASS, dist_opt=args.metric_name, device=dev,
               seed=1234, image_syn=syn, classes=my_classes, **extra)
     if args.path == "dropin":
         d = Distiller(images_all, indices_class, net, **kw)
     else:
-        d = FusedDistiller(images_all, indices_class, net, graph=(args.path == "graph"), defer_loss=(args.path == "graph" and args.defer_loss), **kw)
+        d = FusedDistiller(images_all, indices_class, net, graph=(args.path == "graph"), defer_loss=(args.path == "graph" and args.defer_loss), **kw,
+                           **split_kw)
 
     # ---- live timing of the dominant kernel: the Cin=128 sparse convolution forward (fp32 MFMA) ----
     BIG = 65536   # rows from which the 128-channel launches run k_conv128_rows<4> (dd3d_conv_schedule_tile_rows)
@@ -260,7 +280,7 @@ def main():
                                                             f"ipc={args.ipc} x {NUM_POINTS} pts, MEConvExp, dist_opt={args.metric_name}") if args.config != "cfg4" else
                                                            (f"cfg4: ModelNet40-shaped ellipsoid shells, 40 classes x {REAL_PER_CLASS} real clouds x 1024 pts, voxel 0.05, "
                                                             f"ipc={args.ipc}, MEConvExp(num_classes=40, dense_extent=12^3), dist_opt={args.metric_name}"),
-                                               "parallelism": f"class-sharded x{world}",
+                                               "parallelism": f"class-sharded x{world}" + (f", real batches split x{split_kw['real_part'][1]}" if split_kw else ""),
                                                "path": {"graph": "class-batched step, one HIP graph replay per step", "fused": "class-batched step, eager launches",
                                                         "dropin": "drop-in autograd loop"}[args.path]},
                "loss": loss_value, "roofline": roof, "step_work": step_work, "hbm": hbm if args.path != "dropin" else None}

@@ -21,10 +21,22 @@ def is_distributed() -> bool:
     return dist.is_available() and dist.is_initialized()
 
 
+def _all_reduce(t: torch.Tensor, op, group=None):
+    """all_reduce in place.  RCCL reduces device tensors directly; under gloo (the CPU tests, and the two-ranks-on-one-GPU test) a device
+    tensor is staged through the host."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+    return t
+
+
 def reduce_loss(loss: torch.Tensor) -> torch.Tensor:
     """Sum of the per-rank matching losses, in place; a no-op for a single process."""
     if is_distributed():
-        dist.all_reduce(loss, op=dist.ReduceOp.SUM)
+        _all_reduce(loss, dist.ReduceOp.SUM)
     return loss
 
 
@@ -33,7 +45,7 @@ def max_over_ranks(seconds: float, device) -> float:
     if not is_distributed():
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    _all_reduce(t, dist.ReduceOp.MAX)
     return float(t.item())
 
 
@@ -46,7 +58,7 @@ def gather_synthetic(image_syn: torch.Tensor, ipc: int, num_classes: int) -> tor
     out = torch.zeros_like(image_syn)
     for c in owned_classes(num_classes, rank, world):
         out[c * ipc:(c + 1) * ipc] = image_syn[c * ipc:(c + 1) * ipc]
-    dist.all_reduce(out, op=dist.ReduceOp.SUM)
+    _all_reduce(out, dist.ReduceOp.SUM)
     return out
 
 
@@ -80,5 +92,5 @@ def all_reduce_in(group):
     """exchange(flat) for FusedDistiller: sum the flat buffer of partial real-batch gradients over the ranks of ``group`` (the ranks that
     share a class shard), in place -- RCCL over xGMI on the GPUs, gloo in the tests.  Called outside graph capture."""
     def exchange(flat: torch.Tensor):
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        _all_reduce(flat, dist.ReduceOp.SUM, group)
     return exchange
