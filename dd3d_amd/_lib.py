@@ -78,6 +78,7 @@ _SIGS = {
     "dd3d_scale_rows_by_group": (I32, [P, P, P, I32, I64, I32, P, P]),
     "dd3d_sparse_linear_ws_bytes": (I64, [I64, I32]),
     "dd3d_sparse_linear_fwd": (I32, [P, P, P, I64, P, I32, I32, P, P, P, I32, P, P, P, I64, P]),
+    "dd3d_classifier_head": (I32, [P, P, P, I64, P, I32, I32, P, P, P, I32, P, P, P, I32, I32, P, P, P, P, P, P, P, P, I64, P]),
     "dd3d_sparse_linear_bwd_x": (I32, [P, P, P, I64, P, I32, I32, P, P, P, I32, I32, P, P]),
     "dd3d_sparse_linear_bwd_w": (I32, [P, P, P, I32, I32, P, I32, I32, I32, P, P, I64, P]),
     "dd3d_classifier_layout": (I32, [P, I32, I32, I32, I32, I32, P, P]),

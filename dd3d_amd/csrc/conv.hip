@@ -25,7 +25,11 @@ __host__ __device__ __forceinline__ int chunk3(int M) {
 }
 __host__ __device__ __forceinline__ int chunk128(int M) {
     int ch = (((M > 0 ? M : 1) + 255) / 256 + 31) / 32 * 32;
+#ifdef CH128_LO
+    const int lo = M >= 65536 ? CH128_LO : 128;
+#else
     const int lo = M >= 65536 ? 512 : 128;  // small launches (a synthetic batch, one class per GPU) need many short chunks to fill the CUs
+#endif
     return ch < lo ? lo : ch;
 }
 // slots needed for ANY row count <= bound: the chunk size is smallest (64 / 512) when there are few rows
@@ -426,131 +430,204 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // Cin = Cout = 128 backward-weight: one workgroup per (row chunk, offset k) -> partial slab [128][128]
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_conv128_bww(const float* __restrict__ X, const float* __restrict__ dY, const int* __restrict__ nbr, int64_t ld,
+// *mask |= bit k for every offset k that some row below group_row_off[G] has (mask zeroed before): k_conv128_bww launches a bound-sized
+// grid over (chunk, offset) and the offsets that exist nowhere -- 18 of 27 for flat clouds -- must cost their workgroups nothing.
+__global__ __launch_bounds__(256) void k_offset_mask(const int* __restrict__ nbr, int64_t ld, int K, const int* __restrict__ group_row_off, int G,
+                                                     unsigned* __restrict__ mask) {
+    const int M = group_row_off[G];
+    unsigned m = 0;
+    for (int row = blockIdx.x * 256 + threadIdx.x; row < M; row += gridDim.x * 256) {
+        int v[27];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) v[k] = nbr[(int64_t)min(k, K - 1) * ld + row];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) m |= (unsigned)(k < K && v[k] >= 0) << k;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m |= __shfl_xor(m, o, 64);
+    if ((threadIdx.x & 63) == 0 && m) atomicOr(mask, m);
+}
+
+__global__ __launch_bounds__(256, 3) void k_conv128_bww(const float* __restrict__ X, const float* __restrict__ dY, const int* __restrict__ nbr, int64_t ld,
                                                      int K, const int* __restrict__ group_row_off, int G, float* __restrict__ slabs,
-                                                     int* __restrict__ slab_valid) {
+                                                     int* __restrict__ slab_valid, const unsigned* __restrict__ active) {
     // The (in,out) pairs of offset k inside the chunk are first COMPACTED (stable ballot scan, 1024 rows per window), so the matrix
-    // cores only see rows that have a neighbour; the contraction then runs over 32 pairs at a time.
-    __shared__ f32x4 As4[32 * 32];
-    __shared__ f32x4 Ds4[32 * 32];
-    __shared__ int s_row[1024], s_nb[1024], s_wc[4];
+    // cores only see rows that have a neighbour; the contraction then runs over 32 pairs per step, in the shape of k_conv128_rows:
+    // wave w owns input channels [32w, 32w+32) and all 128 output channels (four 32x32 accumulators); its A operand -- X^T of the
+    // step's 32 gathered rows, one float per lane and row pair -- goes global -> registers; the 32 dY rows of the step (16 KB) are
+    // shared by the four waves through a double-buffered LDS chunk: ONE barrier per step, the loads of step s+1 in flight under the
+    // 64 MFMAs of step s and issued between them.
+    __shared__ f32x4 Bs4[2][32 * 32];
+    __shared__ __align__(16) int s_row[1024 + 32], s_nb[1024 + 32];
+    __shared__ int s_wc[16];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int i32 = lane & 31, h = lane >> 5;
-    const int wm0 = (wid >> 1) * 64, wn0 = (wid & 1) * 64;
-    const int c = blockIdx.x, k = blockIdx.y;
+    // blockIdx.y = index among the offsets present anywhere (k_offset_mask); the grid's x extent is a multiple of 8, so the workgroups
+    // of one chunk -- which read the same dY rows and nearly the same X rows -- land on one XCD and share its L2
+    unsigned am = *active;
+    if ((int)blockIdx.y >= __popc(am)) return;
+    for (int j = 0; j < (int)blockIdx.y; ++j) am &= am - 1;
+    const int c = blockIdx.x, k = __builtin_ctz(am);
     int g, r0, r1;
     const int CH = chunk128(group_row_off[G]);
     if (!resolve_chunk(c, group_row_off, G, CH, &g, &r0, &r1)) return;
     const int* nk = nbr + (int64_t)k * ld;
 
-    f32x16 acc[2][2];
+    f32x16 acc[4];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int n = 0; n < 4; ++n)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-    const f32x4* X4 = (const f32x4*)X;
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    const float* Xc = X + wid * 32 + i32;  // this lane's input channel
     const f32x4* D4 = (const f32x4*)dY;
-    const float* As = (const float*)As4;
-    const float* Ds = (const float*)Ds4;
     bool have_any = false;
+    PROF_T(pt0);
+#ifdef DD3D_CONV_PROF
+    long long t_steps = 0, n_steps = 0, sg1 = 0, sg2 = 0, sg3 = 0;
+#endif
 
     for (int wb = r0; wb < r1; wb += 1024) {
-        int total = 0;
+        // ---- compaction of the window: all table reads first, one pass of ballots ----
+        int nbv[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            int row = wb + j * 256 + tid;
-            int nb = row < r1 ? nk[row] : -1;
-            unsigned long long bal = __ballot(nb >= 0);
-            if (lane == 0) s_wc[wid] = __popcll(bal);
-            __syncthreads();
-            int base = total, all = 0;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                int x = s_wc[w];
-                if (w < wid) base += x;
-                all += x;
-            }
-            if (nb >= 0) {
-                int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-                s_row[pos] = row;
-                s_nb[pos] = nb;
-            }
-            total += all;
-            __syncthreads();
+            const int row = wb + j * 256 + tid;
+            nbv[j] = row < r1 ? nk[row] : -1;
         }
-        if (total) have_any = true;
-        // 32 compacted pairs per MFMA block; the rows of block sb+32 are fetched into registers while the matrix cores work on sb
-        f32x4 ra[4], rd[4];
-        auto fetch = [&](int sb) {
+        __syncthreads();  // the previous window's lists are no longer read
+        unsigned long long bal[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int idx = j * 256 + tid;
-                const int e = min(sb + (idx >> 5), total - 1);  // clamped: branch-free, all 8 loads in flight
-                ra[j] = X4[(int64_t)s_nb[e] * 32 + (idx & 31)];
-                rd[j] = D4[(int64_t)s_row[e] * 32 + (idx & 31)];
-            }
-        };
-        auto stage = [&](int sb) {
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int idx = j * 256 + tid;
-                const bool ok = sb + (idx >> 5) < total;
-                As4[idx] = ok ? ra[j] : zero;
-                Ds4[idx] = ok ? rd[j] : zero;
-            }
-        };
-        if (total) {
-            fetch(0);
-            stage(0);
+        for (int j = 0; j < 4; ++j) {
+            bal[j] = __ballot(nbv[j] >= 0);
+            if (lane == 0) s_wc[j * 4 + wid] = __popcll(bal[j]);
         }
         __syncthreads();
-        for (int sb = 0; sb < total; sb += 32) {
-            const bool more = sb + 32 < total;
-            if (more) fetch(sb + 32);
+        int total = 0, base[4];
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                float a[2], b[2];
+        for (int q = 0; q < 16; ++q) {
+            const int x = s_wc[q];
 #pragma unroll
-                for (int m = 0; m < 2; ++m) a[m] = As[(h * 16 + s) * 128 + wm0 + m * 32 + i32];
-#pragma unroll
-                for (int n = 0; n < 2; ++n) b[n] = Ds[(h * 16 + s) * 128 + wn0 + n * 32 + i32];
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
-            }
-            __syncthreads();
-            if (more) stage(sb + 32);
-            __syncthreads();
+            for (int j = 0; j < 4; ++j)
+                if (q == j * 4 + wid) base[j] = total;
+            total += x;
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (nbv[j] >= 0) {
+                const int pos = base[j] + __popcll(bal[j] & ((1ull << lane) - 1ull));
+                s_row[pos] = wb + j * 256 + tid;
+                s_nb[pos] = nbv[j];
+            }
+        if (total == 0) continue;  // (uniform)
+        have_any = true;
+        __syncthreads();
+        if (tid < 32) {  // ... the tail of the last step reads the last pair again; its A operand is zeroed at use)
+            s_row[total + tid] = s_row[total - 1];
+            s_nb[total + tid] = s_nb[total - 1];
+        }
+        __syncthreads();
+        // pairs past the end of the list (the last step's tail): clamped to the last pair, their A operand is zeroed at use
+        const int steps = (total + 31) / 32, last = total - 1;
+        float cur[16], nxt[16];
+        f32x4 rb[4];
+        {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) cur[q] = Xc[(int64_t)s_nb[min(h * 16 + q, last)] * 128];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Bs4[0][j * 256 + tid] = D4[(int64_t)s_row[min(j * 8 + (tid >> 5), last)] * 32 + (tid & 31)];
+        }
+        __syncthreads();
+        int buf = 0;
+        PROF_T(q0);
+        for (int sb = 0; sb < steps; ++sb) {
+            // the next step (the last one "prefetches" itself again: one code path, see k_conv128_rows)
+            PROF_T(u0);
+            const int nbase = (sb + 1 < steps ? sb + 1 : sb) * 32;
+            const int live = total - sb * 32 - h * 16;  // pairs of this lane's half that exist in this step
+            const f32x4* Bp = &Bs4[buf][(h * 16) * 32 + i32];
+            // the next step's rows: all of its loads go out in the first half of this step (the step ends waiting for them: a load
+            // issued behind the last MFMAs would expose its whole latency)
+            const int4* ia = (const int4*)(s_nb + nbase + h * 16);  // (the lists are padded by 32 entries: no clamp on the address ...
+            const int* ib = s_row + nbase + (tid >> 5);
+            f32x4 b0 = Bp[0], b1 = Bp[32];
+#pragma unroll
+            for (int q = 0; q < 16; q += 2) {
+                f32x4 n0 = b0, n1 = b1;
+                if (q + 2 < 16) n0 = Bp[(q + 2) * 32], n1 = Bp[(q + 3) * 32];
+                if (q < 8) {
+                    const int4 ix = ia[q / 2];
+                    nxt[2 * q] = Xc[(int64_t)ix.x * 128];
+                    nxt[2 * q + 1] = Xc[(int64_t)ix.y * 128];
+                    nxt[2 * q + 2] = Xc[(int64_t)ix.z * 128];
+                    nxt[2 * q + 3] = Xc[(int64_t)ix.w * 128];
+                    rb[q / 2] = D4[(int64_t)ib[q / 2 * 8] * 32 + (tid & 31)];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const float a0 = q < live ? cur[q] : 0.f, a1 = q + 1 < live ? cur[q + 1] : 0.f;
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[n], acc[n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[n], acc[n], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                b0 = n0, b1 = n1;
+            }
+            PROF_T(u1);
+            buf ^= 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Bs4[buf][j * 256 + tid] = rb[j];
+            PROF_T(u2);
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 16; ++q) cur[q] = nxt[q];
+#ifdef DD3D_CONV_PROF
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            PROF_T(u3);
+            PROF_ADD(sg1, u0, u1);
+            PROF_ADD(sg2, u1, u2);
+            PROF_ADD(sg3, u2, u3);
+        }
+        PROF_T(q1);
+        PROF_ADD(t_steps, q0, q1);
+        PROF_ADD(n_steps, 0, steps);
     }
     if (!have_any) {
         if (tid == 0) slab_valid[(int64_t)c * K + k] = 0;  // every resolved (chunk, offset) writes its flag: no memset of the flags
         return;
     }
-    float* slab = slabs + ((int64_t)c * K + k) * (128 * 128);
+    // C/D layout of a 32x32 block: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); block n, lane col i32 <-> output channel 4*i32 + n
+    f32x4* slab4 = (f32x4*)(slabs + ((int64_t)c * K + k) * (128 * 128));
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int ci = wm0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                slab[ci * 128 + wn0 + n * 32 + i32] = acc[m][n][r];
-            }
+    for (int r = 0; r < 16; ++r) {
+        const int ci = wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+        slab4[ci * 32 + i32] = v;
+    }
     if (tid == 0) slab_valid[(int64_t)c * K + k] = 1;
+#ifdef DD3D_CONV_PROF
+    {
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+        if (lane == 0 && wid == 0 && lin < 4096) {  // [start, end, time in step loops, steps, HW_ID, XCC_ID]
+            long long* o = g_prof + (int64_t)lin * 8;
+            o[0] = pt0, o[1] = wall_clock64(), o[2] = t_steps, o[3] = n_steps;
+            o[4] = __builtin_amdgcn_s_getreg(4 | (31 << 11)), o[5] = __builtin_amdgcn_s_getreg(20 | (31 << 11)), o[6] = sg1 | (sg2 << 32), o[7] = sg3;
+        }
+    }
+#endif
 }
 
 // dW[g][k][e] = sum over the valid slabs of group g.  4 slot-lanes walk the slots c = first+lane, first+lane+4, ... (4 independent chains), then the lanes are combined in lane order: deterministic.
 __global__ __launch_bounds__(256) void k_slab_reduce(const f32x4* __restrict__ slabs, const int* __restrict__ slab_valid,
-                                                     const int* __restrict__ group_row_off, int G, int cin3, int K, int elems4, f32x4* __restrict__ dW) {
+                                                     const int* __restrict__ group_row_off, int G, int cin3, int K, int elems4, f32x4* __restrict__ dW,
+                                                     const unsigned* __restrict__ active) {
     __shared__ f32x4 s_red[256];
     const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + el;
     const int k = blockIdx.y, g = blockIdx.z;
+    if (active && !((*active >> k) & 1u)) {  // an offset no row has: no slab of it was written (nor its flags)
+        if (sl == 0 && e < elems4) dW[((int64_t)g * K + k) * elems4 + e] = f32x4{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
     const int CH = cin3 ? chunk3(group_row_off[G]) : chunk128(group_row_off[G]);
     int first = 0;
     for (int j = 0; j < g; ++j) first += (group_row_off[j + 1] - group_row_off[j] + CH - 1) / CH;
@@ -883,7 +960,7 @@ DD3D_API int64_t dd3d_conv_bwd_weight_ws_bytes(int64_t M_out, int G, int K, int 
     int64_t slots = Cin == 3 ? max_slots3(M_out, G) : max_slots128(M_out, G);
     int64_t nslab = (Cin == 3) ? slots : slots * K;
     int64_t per = (Cin == 3) ? (int64_t)K * 3 * Cout : (int64_t)Cin * Cout;
-    return align_up64(nslab * per * 4, 256) + align_up64(nslab * 4, 256);
+    return align_up64(nslab * per * 4, 256) + align_up64(nslab * 4, 256) + 256;  // slabs, their flags, the mask of offsets present anywhere
 }
 
 // Y[M_out,Cout] = sum_k X[nbr[k'][o]] . Wmat[k],  k' = mirror ? K-1-k : k.   Wmat is [K,Cin,Cout] row-major.
@@ -991,19 +1068,24 @@ DD3D_API int dd3d_conv_bwd_weight(const float* X, int Cin, const float* dY, int 
     int64_t per = (Cin == 3) ? (int64_t)K * 3 * Cout : (int64_t)Cin * Cout;
     float* slabs = (float*)ws;
     int* valid = (int*)((char*)ws + align_up64(nslab * per * 4, 256));
+    unsigned* active = (unsigned*)((char*)valid + align_up64(nslab * 4, 256));
     if (M_out > 0) {
         if (!X || !dY || !nbr) return DD3D_EARG;
         if (Cin == 3)
             k_conv3_bww<<<dim3((unsigned)slots), 256, 0, st>>>(X, dY, nbr, ld, group_row_off, G, slabs, valid);
         else
-            k_conv128_bww<<<dim3((unsigned)slots, K), 256, 0, st>>>(X, dY, nbr, ld, K, group_row_off, G, slabs, valid);
+            {
+            DD3D_HIP(hipMemsetAsync(active, 0, 4, st));
+            k_offset_mask<<<dim3(128), 256, 0, st>>>(nbr, ld, K, group_row_off, G, active);
+            k_conv128_bww<<<dim3((unsigned)(ceil_div64(slots, 8) * 8), K), 256, 0, st>>>(X, dY, nbr, ld, K, group_row_off, G, slabs, valid, active);
+        }
     }
     if (Cin == 3)
         k_slab_reduce<<<dim3((unsigned)ceil_div64(per / 4, 64), 1, G), 256, 0, st>>>((const f32x4*)slabs, valid, group_row_off, G, 1, 1, (int)(per / 4),
-                                                                                     (f32x4*)dW);
+                                                                                     (f32x4*)dW, nullptr);
     else
         k_slab_reduce<<<dim3((unsigned)ceil_div64(per / 4, 64), K, G), 256, 0, st>>>((const f32x4*)slabs, valid, group_row_off, G, 0, K, (int)(per / 4),
-                                                                                     (f32x4*)dW);
+                                                                                     (f32x4*)dW, M_out > 0 ? active : nullptr);
     DD3D_CHECK_LAUNCH();
     return 0;
 }

@@ -256,6 +256,82 @@ __global__ void k_group_sum_rows(const float* __restrict__ v, const int* __restr
     if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
 
+// Classifier head in ONE launch (after k_sl_fwd_part): logits = sum of the voxel partials (+ bias), softmax cross entropy with its
+// logit gradient, and the two per-group sums -- mean CE per group and the bias gradient sum_b dlogits[b][:] -- that k_sl_fwd_sum,
+// k_softmax_ce, k_group_sum and k_group_sum_rows compute as four dependent launches (~5 us of dispatch latency each on the critical path
+// of a step).  Workgroup (x, g) takes clouds [64 x, 64 x + 64) of group g; the last workgroup of a group to finish (a counter per group,
+// left at zero again for the next launch) adds the group's rows up in exactly the order of k_group_sum / k_group_sum_rows, so the results
+// are the same bits.
+__global__ __launch_bounds__(256) void k_cls_head(const float* __restrict__ part, const int* __restrict__ seg_off, int J, const float* __restrict__ bias,
+                                                  const int* __restrict__ labels, const int* __restrict__ group_cloud_off, float* __restrict__ logits,
+                                                  float* __restrict__ prob, float* __restrict__ dlogits, float* __restrict__ cloud_loss,
+                                                  float* __restrict__ loss_g, float* __restrict__ bias_grad /*[G][J] or null*/, int* __restrict__ counter) {
+    __shared__ int s_last;
+    const int g = blockIdx.y, tid = threadIdx.x;
+    const int b0 = group_cloud_off[g], b1 = group_cloud_off[g + 1];
+    const int c0 = b0 + blockIdx.x * 64, c1 = min(c0 + 64, b1);
+    if (c0 >= b1 && !(blockIdx.x == 0 && b1 == b0)) return;  // (an empty group: its first workgroup writes the zeros)
+    for (int t = tid; t < (c1 - c0) * J; t += 256) {         // k_sl_fwd_sum: one (cloud, column) per thread, rows added in order
+        const int b = c0 + t / J, j = t % J;
+        float s = 0.f;
+        int v = seg_off[b];
+        const int v1 = seg_off[b + 1];
+        for (; v + 8 <= v1; v += 8) {
+            float x[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x[q] = part[(int64_t)(v + q) * J + j];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += x[q];
+        }
+        for (; v < v1; ++v) s += part[(int64_t)v * J + j];
+        logits[(int64_t)b * J + j] = bias ? s + bias[j] : s;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (tid < c1 - c0) {  // k_softmax_ce: one cloud per thread
+        const int b = c0 + tid;
+        const float inv = 1.0f / (float)max(b1 - b0, 1);
+        const float* z = logits + (int64_t)b * J;
+        float m = z[0];
+        for (int j = 1; j < J; ++j) m = fmaxf(m, z[j]);
+        float se = 0.f;
+        for (int j = 0; j < J; ++j) se += expf(z[j] - m);
+        const float lse = m + logf(se);
+        const int y = labels[b];
+        for (int j = 0; j < J; ++j) {
+            const float p = expf(z[j] - lse);
+            if (prob) prob[(int64_t)b * J + j] = p;
+            dlogits[(int64_t)b * J + j] = (p - (j == y ? 1.f : 0.f)) * inv;
+        }
+        cloud_loss[b] = (lse - z[y]) * inv;
+    }
+    // the group's last workgroup sums its rows
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        const int nwg = max((b1 - b0 + 63) / 64, 1);
+        const int done = atomicAdd(&counter[g], 1) + 1;
+        s_last = done == nwg;
+        if (s_last) counter[g] = 0;  // every workgroup of the group has passed its atomic: ready for the next launch
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    const int lane = tid & 63, w = tid >> 6;
+    for (int col = w; col <= J; col += 4) {  // column J = the cloud losses
+        if (col < J && !bias_grad) continue;
+        if (col == J && !loss_g) continue;
+        float s = 0.f;
+        for (int b = b0 + lane; b < b1; b += 64)
+            s += col < J ? dlogits[(int64_t)b * J + col] : cloud_loss[b];  // (written by other workgroups: read behind the fence above)
+        s = wave_sum(s);
+        if (lane == 0) {
+            if (col < J) bias_grad[(int64_t)g * J + col] = s;
+            else loss_g[g] = s;
+        }
+    }
+}
+
 // second order: dlogits = (softmax(z) - onehot)/B_g ; given u = dL/d(dlogits) -> dz = p * (u - <p,u>) / B_g
 __global__ void k_softmax_ce_bwd2(const float* __restrict__ prob, const float* __restrict__ u, const float* __restrict__ u_group /*[G][J] or null*/,
                                   const int* __restrict__ group_cloud_off, int G, int J, float* __restrict__ dz) {
@@ -584,6 +660,27 @@ DD3D_API int dd3d_sparse_linear_fwd(const float* F, const int32_t* site, const i
         k_sl_fwd_part<<<dim3((unsigned)(ceil_div64(M_bound, 16) < 2048 ? ceil_div64(M_bound, 16) : 2048)), 256, 0, st>>>(F, site, (const int4*)coords, seg_off + B, cloud_group, Wl, mk_stride(strides),
                                                                              J, (float*)ws);
     k_sl_fwd_sum<<<dim3((unsigned)ceil_div64((int64_t)B * J, 256)), 256, 0, st>>>((const float*)ws, seg_off, B, J, bias, out);
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}
+
+// dd3d_sparse_linear_fwd + dd3d_softmax_ce + dd3d_group_sum_rows(dlogits) in two launches (same bits): logits[B,J], prob[B,J] (nullable),
+// dlogits[B,J], cloud_loss[B] (scratch), loss_g[G] (nullable), bias_grad[G,J] (nullable).  counters: G ints, zero before the FIRST call (the
+// kernel leaves them zero).  max_per_group >= clouds of the largest group.
+DD3D_API int dd3d_classifier_head(const float* F, const int32_t* site, const int32_t* coords, int64_t M_bound, const int32_t* seg_off, int B, int C,
+                                  const int32_t* cloud_group, const float* Wl, const int64_t* strides, int J, const float* bias, const int32_t* labels,
+                                  const int32_t* group_cloud_off, int G, int max_per_group, float* logits, float* prob, float* dlogits,
+                                  float* cloud_loss, float* loss_g, float* bias_grad, int32_t* counters, void* ws, int64_t ws_bytes, void* stream) {
+    if (B < 0 || C != 128 || J <= 0 || M_bound < 0 || !strides || G <= 0 || max_per_group <= 0 || !group_cloud_off || !counters) return DD3D_EARG;
+    if (B == 0) return 0;
+    if (!F || !site || !coords || !seg_off || !Wl || !logits || !labels || !dlogits || !cloud_loss) return DD3D_EARG;
+    if (!ws || ws_bytes < dd3d_sparse_linear_ws_bytes(M_bound, J)) return DD3D_EWS;
+    hipStream_t st = (hipStream_t)stream;
+    if (M_bound > 0)
+        k_sl_fwd_part<<<dim3((unsigned)(ceil_div64(M_bound, 16) < 2048 ? ceil_div64(M_bound, 16) : 2048)), 256, 0, st>>>(F, site, (const int4*)coords, seg_off + B, cloud_group, Wl, mk_stride(strides),
+                                                                             J, (float*)ws);
+    k_cls_head<<<dim3((unsigned)((max_per_group + 63) / 64), (unsigned)G), 256, 0, st>>>((const float*)ws, seg_off, J, bias, labels, group_cloud_off, logits, prob,
+                                                                                         dlogits, cloud_loss, loss_g, bias_grad, counters);
     DD3D_CHECK_LAUNCH();
     return 0;
 }

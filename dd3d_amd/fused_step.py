@@ -58,6 +58,17 @@ def conv_kernel_gradient(X, Cin, dY, nbr, ld, M, gro, G, dev, seg=None, B=0, err
     return dW
 
 
+_COUNTERS = {}
+
+
+def _group_counters(dev, G):
+    """G zero ints for the kernels that elect a group's last workgroup (they leave the counters at zero): one buffer per device, zeroed once."""
+    buf = _COUNTERS.get(dev)
+    if buf is None or buf.numel() < G:   # (the first step of a distiller is never captured)
+        buf = _COUNTERS[dev] = torch.zeros(max(G, 1024), dtype=_I32, device=dev)
+    return buf
+
+
 class _Pass:
     """Forward + first-order backward of MEConvExp over ONE class-batched set of clouds -- the synthetic clouds first, then the real
     ones -- and the second-order backward over the synthetic prefix.
@@ -68,7 +79,7 @@ class _Pass:
     pass is the same kernels called on the first ``B_syn`` clouds with the prefix's row counts (``seg_off[B_syn]``, on the device)."""
 
     def __init__(self, net, coords, B, G, cloud_group, group_cloud_off, B_syn, N_syn, side, n_dev=None, static=False, pt_off=None, max_points=0,
-                 extent=None, side2=None, stash=None, Gs=None, dl_scale=None, gmin_floor=None):
+                 extent=None, side2=None, stash=None, Gs=None, dl_scale=None, gmin_floor=None, max_per_group=0):
         """Phase 1 (no host sync): every coordinate map, enqueued on the current stream.
         ``static``: never read a size back -- every launch covers its bound and takes the true row count from the device
         (``n_dev`` = number of valid rows of ``coords``), so the pass can be captured into a HIP graph."""
@@ -78,6 +89,7 @@ class _Pass:
         # shared with other ranks, FusedDistiller's second sharding level); dl_scale [B - B_syn, 1]: weight of every real cloud's logit
         # gradient (a rank holding n_part of a class's n clouds contributes sum(CE) / n, not its own mean)
         self.B_syn, self.N_syn, self.Gs, self.dl_scale = B_syn, N_syn, (G // 2 if Gs is None else Gs), dl_scale
+        self.max_per_group = max_per_group if max_per_group > 0 else B   # clouds of the largest group (a bound)
         self.cloud_group, self.gco = cloud_group, group_cloud_off
         self.static, self.side, self.side2 = static, side, side2 if side2 is not None else side
         # dense() placement over `extent` sites per axis: the network's dense extent, or the (smaller) box the voxels can actually reach
@@ -182,11 +194,14 @@ class _Pass:
         L.call("dd3d_inorm_arp_fwd", L.ptr(Y1), L.ptr(seg2), B, 128, L.ptr(xh1), L.ptr(is1), L.ptr(w5), L.ptr(b5), L.ptr(p1), pl1, 8,
                L.ptr(dp.seg_off), L.ptr(P1), L.ptr(arg1), st)
         logits = self.logits = _empty((B, J), dev)
-        sl_fwd_call(P1, dp, None, Wsm, sst, J, cls_b, logits)
         prob, dl = self.prob, self.dl = _empty((B, J), dev), _empty((B, J), dev)
         closs, self.ce = _empty((B,), dev), _empty((G,), dev)
-        L.call("dd3d_softmax_ce", L.ptr(logits), L.ptr(labels), L.ptr(cloud_group), L.ptr(group_cloud_off), G, B, J, L.ptr(prob), L.ptr(dl),
-               L.ptr(closs), L.ptr(self.ce), st)
+        # classifier, cross entropy, its logit gradient and the per-group bias gradient: two launches (dd3d_classifier_head)
+        g_cb = _empty((G, J), dev)
+        ws = L.workspace(int(L.lib.dd3d_sparse_linear_ws_bytes(dp.M_bound, J)), dev)
+        L.call("dd3d_classifier_head", L.ptr(P1), L.ptr(dp.site), L.ptr(dp.C), dp.M_bound, L.ptr(dp.seg_off), B, 128, None, L.ptr(Wsm), sst, J,
+               L.ptr(cls_b), L.ptr(labels), L.ptr(group_cloud_off), G, int(self.max_per_group), L.ptr(logits), L.ptr(prob), L.ptr(dl), L.ptr(closs),
+               L.ptr(self.ce), None if self.dl_scale is not None else L.ptr(g_cb), L.ptr(_group_counters(dev, G)), L.ptr(ws), ws.numel(), st)
         if self.dl_scale is not None:   # every first-order gradient below is linear in dl
             dl[self.B_syn:].mul_(self.dl_scale)
 
@@ -196,8 +211,8 @@ class _Pass:
         main, side = torch.cuda.current_stream(dev), self.side
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            g_cb = _empty((G, J), dev)
-            L.call("dd3d_group_sum_rows", L.ptr(dl), L.ptr(group_cloud_off), G, J, L.ptr(g_cb), L.stream())
+            if self.dl_scale is not None:   # (the bias gradient of the SCALED logit gradients)
+                L.call("dd3d_group_sum_rows", L.ptr(dl), L.ptr(group_cloud_off), G, J, L.ptr(g_cb), L.stream())
             g_cw = _empty((G, J, 128 * S), dev)
             pst = (ctypes.c_int64 * 4)(J * 128 * S, 128 * S, S, 1)
             L.call("dd3d_sparse_linear_bwd_w", L.ptr(dl), L.ptr(P1), L.ptr(dp.vox_at), S, B, L.ptr(group_cloud_off), G, 128, J, L.ptr(g_cw), pst,
@@ -728,7 +743,7 @@ class FusedDistiller:
                 "labels": torch.cat([self.syn_labels, rb["labels"].to(_I32)]), "num_clouds": Bs + int(rb["num_clouds"]),
                 "cloud_group": torch.cat([self.syn_group, rb["cloud_group"] + G]),
                 "group_cloud_off": torch.cat([self.syn_gco, rb["group_cloud_off"][1:] + Bs]),
-                "pt_off": torch.cat([self.syn_pt_off, pt[1:] + Ns]), "n_dev": None, "extent": rb.get("extent"), "gmin_floor": rb.get("gmin_floor")}
+                "pt_off": torch.cat([self.syn_pt_off, pt[1:] + Ns]), "n_dev": None, "extent": rb.get("extent"), "gmin_floor": rb.get("gmin_floor"), "max_per": rb.get("max_per")}
 
     def _run_deferred(self, stash):
         """The loss-value-only work a deferred step left behind: both convolutions' kernel gradients over the stashed operands (the
@@ -795,7 +810,7 @@ class FusedDistiller:
         transposed_kernel(net.features[4].kernel)
         p = _Pass(net, mb["coordinates"], int(mb["num_clouds"]), G + self.Gr, mb["cloud_group"], mb["group_cloud_off"], G * ipc, G * ipc * npts,
                   self.stream_side, mb.get("n_dev"), static, mb.get("pt_off"), npts, extent, self.stream_side2, stash, Gs=G,
-                  dl_scale=self.dl_scale, gmin_floor=mb.get("gmin_floor"))
+                  dl_scale=self.dl_scale, gmin_floor=mb.get("gmin_floor"), max_per_group=max(ipc, int(mb.get("max_per") or mb["num_clouds"])))
         p.run(mb["features"], mb["labels"], defer=stash is not None)
         gw_syn, gw_real = [None if t is None else t[:G] for t in p.gw], [None if t is None else t[G:] for t in p.gw]
         # Only these entries of gw_syn depend on the synthetic points: IN weights, classifier weight and bias.  For the
@@ -892,7 +907,7 @@ class FusedDistiller:
         L.call("dd3d_gather_clouds", L.ptr(st.pool_xyz), L.ptr(st.pool_off), st.n_pool, L.ptr(st.ids), st.B, self.num_points, st.bound_total,
                Bs, Ns, self.quant, L.ptr(st.coords), L.ptr(st.feats), L.ptr(st.pt_off), L.ptr(st.n), L.ptr(st.err), L.stream())
         mb = {"coordinates": st.coords, "features": st.feats, "labels": st.labels, "num_clouds": Bs + st.B, "cloud_group": st.cloud_group,
-              "group_cloud_off": st.gco, "n_dev": st.n, "pt_off": st.pt_off, "gmin_floor": st.gmin_floor}
+              "group_cloud_off": st.gco, "n_dev": st.n, "pt_off": st.pt_off, "gmin_floor": st.gmin_floor, "max_per": st.max_per}
         with L.ws_scope(self._scope + ("p%d" % parity if self.defer else "")):
             out = yield from self._compute_gen(mb, True, stash)
         if self.defer:

@@ -240,6 +240,17 @@ int dd3d_scale_rows_by_group(const float* ga, const float* gw, const int32_t* gr
  * replaces: SparseTensor.dense() + view(-1,100352) + nn.Linear(100352,10) and their autograd, models/MEConv.py:254-256
  * strides[4] (HOST) = element strides of the weight-like operand over (group, output j, channel c, site s)
  * ------------------------------------------------------------------------------------------------------------------- */
+/* dd3d_sparse_linear_fwd, dd3d_softmax_ce and dd3d_group_sum_rows(dlogits) in two launches instead of five, same bits: logits[B,J],
+ * prob[B,J] (nullable), dlogits[B,J], cloud_loss[B] (scratch), loss_g[G] (nullable), bias_grad[G,J] (nullable) = the classifier-bias
+ * gradient of every group.  counters: G ints, zero before the first call (left zero by every call); max_per_group >= clouds of the
+ * largest group.
+ * replaces: self.classifier(dense) + nn.CrossEntropyLoss + its backward into the logits and the bias, models/MEConv.py:255,
+ * mnist_distill.py:346-349,355-358 */
+int dd3d_classifier_head(const float* F, const int32_t* site, const int32_t* coords, int64_t M_bound, const int32_t* seg_off, int B, int C,
+                         const int32_t* cloud_group, const float* Wl, const int64_t* strides, int J, const float* bias, const int32_t* labels,
+                         const int32_t* group_cloud_off, int G, int max_per_group, float* logits, float* prob, float* dlogits, float* cloud_loss,
+                         float* loss_g, float* bias_grad, int32_t* counters, void* ws, int64_t ws_bytes, void* stream);
+
 /* coords = int32 [M,4] voxel rows (column 0 = cloud index), M_bound = their bound; the true row count is seg_off[B] (device).
  * fwd runs as per-voxel partial products (one wave per voxel) + an ordered per-cloud sum: ws from dd3d_sparse_linear_ws_bytes. */
 int64_t dd3d_sparse_linear_ws_bytes(int64_t M_bound, int J);
