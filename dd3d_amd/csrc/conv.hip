@@ -20,16 +20,12 @@ namespace {
 //   Cin = 128: about 256 row chunks per launch, at least 512 rows each (measured: fewer, larger chunks are slower even when they
 //              fit the resident slots exactly -- the per-chunk compaction phases overlap better across many workgroups)
 __host__ __device__ __forceinline__ int chunk3(int M) {
-    int ch = (((M > 0 ? M : 1) + 511) / 512 + 31) / 32 * 32;
+    int ch = (((M > 0 ? M : 1) + 511) / 512 + 31) / 32 * 32;  // (measured: 1024 / 1536 / 2048 chunks take 80 / 86 / 95 us against 73 us)
     return ch < 64 ? 64 : ch;
 }
 __host__ __device__ __forceinline__ int chunk128(int M) {
     int ch = (((M > 0 ? M : 1) + 255) / 256 + 31) / 32 * 32;
-#ifdef CH128_LO
-    const int lo = M >= 65536 ? CH128_LO : 128;
-#else
     const int lo = M >= 65536 ? 512 : 128;  // small launches (a synthetic batch, one class per GPU) need many short chunks to fill the CUs
-#endif
     return ch < lo ? lo : ch;
 }
 // slots needed for ANY row count <= bound: the chunk size is smallest (64 / 512) when there are few rows

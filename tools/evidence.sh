@@ -3,7 +3,7 @@
 # (roofline kernel + per-kernel table), MFMA-utilisation pass of the roofline kernel, record runs of the other configurations.
 set -o pipefail
 timeout -k 10 500 python bench.py > gpurun_out/bench_default.log 2>&1; rc=$?; tail -1 gpurun_out/bench_default.log | cut -c1-2000; [ $rc -eq 0 ] || exit $rc
-bash tools/prof.sh prof_r01_graph --steps 20 --warmup 3 || exit 1
+bash tools/prof.sh prof_r02_graph --steps 20 --warmup 3 || exit 1
 bash tools/pmc.sh pmc_rows || exit 1
 python tools/pmc_to_json.py gpurun_out/pmc_rows gpurun_out/pmc_rows/summary.json > /dev/null || exit 1
 python tools/pmc_table.py gpurun_out/pmc_rows gpurun_out/pmc_rows/table.md > /dev/null || exit 1
