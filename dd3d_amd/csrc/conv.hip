@@ -84,7 +84,9 @@ __global__ __launch_bounds__(256) void k_conv128(const float* __restrict__ X, co
     if (tid == 0) s_kmask = 0;
     if (tid < TM) {
         const int64_t slot = row0 + tid;
-        s_row[tid] = slot < M_out ? (perm ? perm[slot] : (int)slot) : M_out;
+        int r = slot < M_out ? (perm ? perm[slot] : (int)slot) : M_out;
+        if ((unsigned)r > (unsigned)M_out) r = M_out;  // a row index outside the launch (a corrupted schedule): a dead slot, never an address
+        s_row[tid] = r;
     }
     __syncthreads();
     unsigned mymask = 0;
@@ -264,7 +266,8 @@ __global__ __launch_bounds__(NW * 64) void k_conv128_rows(const float* __restric
     static_assert(NTH == 2 * TM, "two threads per tile slot");
     const int slot_r = tid & (TM - 1), k_first = tid / TM;
     const int64_t slot = row0 + slot_r;
-    const int my_row = slot < M_out ? (perm ? perm[slot] : (int)slot) : M_out;  // slots past the end are dead
+    int my_row = slot < M_out ? (perm ? perm[slot] : (int)slot) : M_out;  // slots past the end are dead
+    if ((unsigned)my_row > (unsigned)M_out) my_row = M_out;                     // (and so is a row index outside the launch)
     unsigned tmask = tile_mask ? tile_mask[tile] : 0x7fffffffu;
     const bool in_order = nbr_sorted && !(tmask >> 31);
     const int* nbr_col = in_order ? nbr_sorted + min(slot, (int64_t)M_out - 1) : nbr + min(my_row, M_out - 1);  // clamped, no branch on the row

@@ -172,19 +172,27 @@ class _Pass:
                L.ptr(P0), L.ptr(arg0), st)
         Y1 = _empty((M1, 128), dev)
         if use_sched:
-            perm1 = _empty((M1,), dev, _I32)
-            tmap1 = _empty((int(L.lib.dd3d_conv_schedule_blocks(M1)),), dev, _I32)
             # the 128-row kernel also takes the table in pattern order and the offsets of every tile (the 32-row one gathers through perm)
             tr = int(L.lib.dd3d_conv_schedule_tile_rows(M1))
-            k1s = _empty((27, ld1), dev, _I32) if tr == 128 else None
-            tmask1 = _empty(((M1 + tr - 1) // tr,), dev, _I32) if tr == 128 else None
             self.side.wait_event(ev_maps)
             with torch.cuda.stream(self.side):
+                # The schedule's outputs are ALLOCATED on the side stream too: its kernels wait for the maps only and run beside the first
+                # layer, so a block that the main stream's allocator pool had just taken back from a tensor of THIS step could still be
+                # in use by a queued main-stream kernel when the side stream writes the schedule into it (measured: intermittent wrong
+                # values and, with the 14 MB pattern-ordered table, illegal addresses in the convolution that gathers through it)
+                perm1 = _empty((M1,), dev, _I32)
+                tmap1 = _empty((int(L.lib.dd3d_conv_schedule_blocks(M1)),), dev, _I32)
+                k1s = _empty((27, ld1), dev, _I32) if tr == 128 else None
+                tmask1 = _empty(((M1 + tr - 1) // tr,), dev, _I32) if tr == 128 else None
                 ws = L.workspace(int(L.lib.dd3d_conv_schedule_ws_bytes(M1)), dev)
                 L.call("dd3d_conv_schedule", L.ptr(k1), ld1, 27, M1, c1, L.ptr(perm1), L.ptr(tmap1), L.ptr(k1s), L.ptr(tmask1), L.ptr(ws), ws.numel(),
                        L.stream())
             self.sched = (perm1, tmap1, k1s, tmask1)
             torch.cuda.current_stream(dev).wait_stream(self.side)
+            if not self.static:
+                for t in self.sched:   # allocated on the side stream, read by both convolution launches on the main one
+                    if t is not None:
+                        t.record_stream(torch.cuda.current_stream(dev))
             L.call("dd3d_conv128_ordered", L.ptr(P0), M1, L.ptr(W1), L.ptr(k1), ld1, 27, M1, c1, 0, L.ptr(perm1), L.ptr(tmap1), L.ptr(k1s), L.ptr(tmask1),
                    L.ptr(Y1), st)
         else:
@@ -262,6 +270,10 @@ class _Pass:
                     t.record_stream(main)
         # order of network.parameters()
         self.gw = [g_W0, g_w1, g_b1, g_W1, g_w5, g_b5, g_cw, g_cb]
+        # Operands that a SIDE stream is still reading when this returns (the two kernel gradients run next to the matching loss and the
+        # second-order pass): they stay referenced by the pass, i.e. until the next step, so the allocator cannot hand their memory to
+        # a main-stream tensor of this step (an intermittent wrong loss VALUE otherwise: 1 in ~60 first steps, measured)
+        self._side_operands = (gY1, gY0, gP1, gP0)
         return self
 
     def _arp_inorm_bwd(self, g_pool, arg, parent, xhat, inv_std, w, b, seg, M_in, B, G, ga_out, ga_clouds, want_gw, ga_prev=None, gw_extra=None,

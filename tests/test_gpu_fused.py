@@ -168,6 +168,14 @@ def test_graph_replay_is_bitwise_the_eager_step(metric, classes):
     sizes = set()
     for step in range(5):
         lg, le = fg.outer_step().item(), fe.outer_step().item()
+        if lg != le:   # name what differs
+            pg, pe = fg.last["passes"][0], fe.last["passes"][0]
+            M0, M1, M2 = fe.row_counts()[0]
+            diff = [n for n, m in (("F0", M0), ("xh0", M0), ("P0", M1), ("xh1", M1), ("P1", M2), ("logits", None), ("dl", None))
+                    if not torch.equal(getattr(pg, n)[:m], getattr(pe, n)[:m])]
+            diff += [f"gw_real[{i}]" for i in range(8) if not torch.equal(fg.last["gw_real"][i], fe.last["gw_real"][i])]
+            diff += [f"gw_syn[{i}]" for i in range(8) if not torch.equal(fg.last["gw_syn"][i], fe.last["gw_syn"][i])]
+            print("differs:", diff, "rows", fg.row_counts(), fe.row_counts())
         assert lg == le, f"step {step}: graph {lg} vs eager {le}"
         assert torch.equal(fg.image_syn, fe.image_syn)
         assert torch.equal(fg.last["grad"], fe.last["grad"])
