@@ -1,6 +1,6 @@
 """Two processes on the one GPU of the box, gloo between them (RCCL needs a GPU per rank): the second sharding level end to end --
-sharding.split_layout, FusedDistiller(real_classes, real_part, exchange=all_reduce_in(group)), two graphs around the all-reduce,
-gather_synthetic -- against the single-process step on the same samples."""
+sharding.split_layout, FusedDistiller(real_classes, real_part, exchange=all_reduce_in(group)) with eager launches, gather_synthetic --
+against the single-process step on the same samples."""
 import os
 import socket
 
@@ -46,7 +46,7 @@ def _work(rank, world, port, q):
     syn = init_synthetic(4, 3, 250, seed=2)
     lay = split_layout(4, rank, world, 2)                     # one shard of four classes, two parts: rank 0 owns classes 0, 2; rank 1 owns 1, 3
     group = dist.new_group(lay["group_ranks"])
-    d = FusedDistiller(images, idx, net, ipc=3, num_classes=4, batch_size=24, device=dev, seed=11, image_syn=syn, dist_opt="ours", graph=True,
+    d = FusedDistiller(images, idx, net, ipc=3, num_classes=4, batch_size=24, device=dev, seed=11, image_syn=syn, dist_opt="ours", graph=False,
                        classes=lay["classes"], real_classes=lay["real_classes"], real_part=lay["real_part"], exchange=all_reduce_in(group))
     losses = []
     log = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", f"split_rank{rank}.log"), "w")
@@ -58,9 +58,9 @@ def _work(rank, world, port, q):
     full = gather_synthetic(d.image_syn, 3, 4)
     ref = None
     if rank == 0:                                             # the unsplit step, same seed = same permutations
-        w = FusedDistiller(images, idx, net, ipc=3, num_classes=4, batch_size=24, device=dev, seed=11, image_syn=syn, dist_opt="ours", graph=True)
+        w = FusedDistiller(images, idx, net, ipc=3, num_classes=4, batch_size=24, device=dev, seed=11, image_syn=syn, dist_opt="ours", graph=False)
         ref = ([float(w.outer_step().item()) for _ in range(4)], w.image_syn.cpu())
-    q.put((rank, lay["classes"], losses, full.cpu(), ref, d._graph is not None and len(d._graphs[0]) == 6))
+    q.put((rank, lay["classes"], losses, full.cpu(), ref, d._graph is None))
     dist.destroy_process_group()
 
 
