@@ -676,3 +676,85 @@ def test_cloud_window_bwd_weight_flags_a_cloud_larger_than_the_window():
     assert int(err.item()) & 16
     assert L.lib.dd3d_conv128_bwd_weight_clouds(L.ptr(X), L.ptr(X), L.ptr(nbr), ld, 27, M, L.ptr(one), 2, L.ptr(gro), 1, L.ptr(dW), L.ptr(err), L.ptr(ws), 16,
                                                 L.stream()) == -3
+
+
+@pytest.mark.parametrize("B,G,J", [(90, 3, 10), (300, 2, 7), (5, 5, 10)])
+def test_classifier_head_is_bitwise_the_separate_entry_points(B, G, J):
+    """dd3d_classifier_head (sparse linear forward + softmax CE + logit gradient + per-group CE and bias gradient, two launches) against
+    dd3d_sparse_linear_fwd, dd3d_softmax_ce and dd3d_group_sum_rows: the same bits, with an empty group, groups of more than 64 clouds
+    (several workgroups per group, one of them elected to sum), twice in a row on the same counters (they must be left at zero)."""
+    import ctypes
+    from dd3d_amd import _lib as L
+    from dd3d_amd.ops import DensePlacement, _site_strides, site_major
+    d = dev()
+    coords = make_coords(B=B, pts=120, extent=28, seed=B)
+    cm = manager(coords, B)
+    sizes = np.diff(np.linspace(0, B, G, dtype=int)).tolist() + [0]            # G - 1 groups and an empty one at the end
+    gco = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device=d)
+    cg = torch.repeat_interleave(torch.arange(G, device=d), torch.tensor(sizes, device=d)).to(torch.int32)
+    dp = DensePlacement(cm, 4, (1, 28, 28), cg, G, gco)
+    cm.sync()
+    M2, S = cm.num_rows(4), dp.S
+    g = torch.Generator().manual_seed(3)
+    F = torch.randn(M2, 128, generator=g).to(d)
+    Wsm = site_major((torch.randn(J, 128 * S, generator=g) * 0.05).to(d), 128, S)
+    sst = _site_strides(J, 128, S)
+    bias = torch.randn(J, generator=g).to(d)
+    labels = torch.randint(0, J, (B,), generator=g).to(d, torch.int32)
+    ws = torch.empty(int(L.lib.dd3d_sparse_linear_ws_bytes(dp.M_bound, J)), dtype=torch.uint8, device=d)
+    # the separate entry points
+    logits, prob, dl, closs = [torch.empty(B, J, device=d) for _ in range(3)] + [torch.empty(B, device=d)]
+    ce, gcb = torch.full((G,), 7.0, device=d), torch.full((G, J), 7.0, device=d)
+    L.call("dd3d_sparse_linear_fwd", L.ptr(F), L.ptr(dp.site), L.ptr(dp.C), dp.M_bound, L.ptr(dp.seg_off), B, 128, None, L.ptr(Wsm), sst, J, L.ptr(bias),
+           L.ptr(logits), L.ptr(ws), ws.numel(), L.stream())
+    L.call("dd3d_softmax_ce", L.ptr(logits), L.ptr(labels), L.ptr(cg), L.ptr(gco), G, B, J, L.ptr(prob), L.ptr(dl), L.ptr(closs), L.ptr(ce), L.stream())
+    L.call("dd3d_group_sum_rows", L.ptr(dl), L.ptr(gco), G, J, L.ptr(gcb), L.stream())
+    counters = torch.zeros(G, dtype=torch.int32, device=d)
+    for _ in range(2):
+        l2, p2, d2, c2 = [torch.full((B, J), 3.0, device=d) for _ in range(3)] + [torch.full((B,), 3.0, device=d)]
+        ce2, gcb2 = torch.full((G,), 3.0, device=d), torch.full((G, J), 3.0, device=d)
+        L.call("dd3d_classifier_head", L.ptr(F), L.ptr(dp.site), L.ptr(dp.C), dp.M_bound, L.ptr(dp.seg_off), B, 128, None, L.ptr(Wsm), sst, J,
+               L.ptr(bias), L.ptr(labels), L.ptr(gco), G, max(sizes), L.ptr(l2), L.ptr(p2), L.ptr(d2), L.ptr(c2), L.ptr(ce2), L.ptr(gcb2),
+               L.ptr(counters), L.ptr(ws), ws.numel(), L.stream())
+        assert torch.equal(l2, logits) and torch.equal(p2, prob) and torch.equal(d2, dl) and torch.equal(c2, closs)
+        assert torch.equal(ce2, ce) and torch.equal(gcb2, gcb)
+        assert int(counters.abs().sum()) == 0
+    assert float(ce[-1]) == 0.0 and float(gcb[-1].abs().sum()) == 0.0      # the empty group
+
+
+def test_cloud_maps_minimum_corner_floor_places_a_part_like_the_whole_batch():
+    """dd3d_cloud_maps(gmin_floor): the even clouds of a batch, given the minimum stride-4 corner of the whole batch's groups, get the dense
+    sites they have in the whole batch (what a rank holding part of a class's real batch needs, MEConv.py:251-254); without the floor
+    at least one group is placed by a different corner."""
+    from dd3d_amd.ops import DensePlacement
+    from dd3d_amd.sparse import CloudCoordinateManager
+    d = dev()
+    B, ext, G = 12, (1, 64, 64), 2
+    coords = make_coords(B=B, pts=80, extent=24, seed=9)
+    coords[:, 2:] += 8.0
+    coords[coords[:, 0] == 1, 2:] *= 0.2           # cloud 1 (odd: not in the part) reaches into the low corner of group 0
+    coords[coords[:, 0] == 9, 2:] *= 0.2           # cloud 9 likewise for group 1
+
+    def maps(c, nb, floor=None):
+        c = c.to(d)
+        cnt = torch.bincount(c[:, 0].long(), minlength=nb)
+        pt = torch.cat([cnt.new_zeros(1), torch.cumsum(cnt, 0)]).to(torch.int32)
+        cg = (torch.arange(nb, device=d) >= nb // 2).to(torch.int32)
+        gco = torch.tensor([0, nb // 2, nb], dtype=torch.int32, device=d)
+        cm = CloudCoordinateManager(c, pt, nb, int(cnt.max()), ext, cg, G, gco, gmin_floor=floor)
+        dp = DensePlacement(cm, 4, ext, cg, G, gco)
+        cm.sync()
+        return cm, dp
+
+    whole, dw = maps(coords, B)
+    keep = (coords[:, 0].long() % 2) == 0
+    part = coords[keep].clone()
+    part[:, 0] = torch.div(part[:, 0], 2, rounding_mode="floor")     # clouds 0, 2, 4, ... renumbered 0, 1, 2, ...
+    (pm, dpm), (nm, dnm) = maps(part, B // 2, dw.gmin.clone()), maps(part, B // 2)
+    assert torch.equal(dpm.gmin, dw.gmin) and not torch.equal(dnm.gmin, dw.gmin)
+    # the stride-4 voxels of cloud 2b in the whole batch = those of cloud b in the part, in the same order
+    M4 = pm.num_rows(4)
+    segw, segp = whole.seg_off(4).tolist(), pm.seg_off(4).tolist()
+    want = torch.cat([dw.site[segw[2 * b]:segw[2 * b + 1]] for b in range(B // 2)])
+    assert torch.equal(dpm.site[:M4], want) and not torch.equal(dnm.site[:M4], want)
+    pm.check(), whole.check()
