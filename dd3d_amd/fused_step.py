@@ -259,7 +259,7 @@ class _Pass:
         # The first layer's kernel gradient feeds nothing but the loss VALUE either: it runs on a stream of its own next to the 128-channel
         # one (bandwidth-bound next to matrix-bound), and the main stream goes on to the matching loss of the differentiable entries and
         # the second-order pass (the caller joins the streams: FusedDistiller._compute)
-        side2 = self.side2
+        side2 = self.side2   # (queued behind the 128-channel kernel gradient on the same stream instead: 1.385 against 1.338 ms)
         if not defer:
             side2.wait_stream(main)
             with torch.cuda.stream(side2):
