@@ -19,8 +19,11 @@ namespace {
 //   Cin = 3  : cheap chunks, aim for ~512 of them (two per CU), at least 64 rows each
 //   Cin = 128: about 256 row chunks per launch, at least 512 rows each (measured: fewer, larger chunks are slower even when they
 //              fit the resident slots exactly -- the per-chunk compaction phases overlap better across many workgroups)
+#ifndef DD3D_CHUNK3_TARGET
+#define DD3D_CHUNK3_TARGET 512
+#endif
 __host__ __device__ __forceinline__ int chunk3(int M) {
-    int ch = (((M > 0 ? M : 1) + 511) / 512 + 31) / 32 * 32;  // (measured: 1024 / 1536 / 2048 chunks take 80 / 86 / 95 us against 73 us)
+    int ch = (((M > 0 ? M : 1) + DD3D_CHUNK3_TARGET - 1) / DD3D_CHUNK3_TARGET + 31) / 32 * 32;
     return ch < 64 ? 64 : ch;
 }
 __host__ __device__ __forceinline__ int chunk128(int M) {
@@ -29,7 +32,7 @@ __host__ __device__ __forceinline__ int chunk128(int M) {
     return ch < lo ? lo : ch;
 }
 // slots needed for ANY row count <= bound: the chunk size is smallest (64 / 512) when there are few rows
-inline int64_t max_slots3(int64_t bound, int G) { return ceil_div64(bound, 64) < 512 + G ? ceil_div64(bound, 64) + G : 512 + G; }
+inline int64_t max_slots3(int64_t bound, int G) { return ceil_div64(bound, 64) < DD3D_CHUNK3_TARGET + G ? ceil_div64(bound, 64) + G : DD3D_CHUNK3_TARGET + G; }
 inline int64_t max_slots128(int64_t bound, int G) { return ceil_div64(bound, 128) < 512 + G ? ceil_div64(bound, 128) + G : 512 + G; }
 
 // ---------------------------------------------------------------------------------------------
@@ -43,6 +46,12 @@ __host__ __device__ __forceinline__ int split_count(int ntile, int smax) {
     // take 57 us split nine ways plus 8 us of summing against 60 us unsplit) and the launch runs unsplit, straight into Y
     const int s = 512 / (ntile > 0 ? ntile : 1);
     return s < 3 ? 1 : (s > smax ? smax : s);
+}
+
+__device__ __forceinline__ unsigned wave_or_u(unsigned m) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m |= __shfl_xor(m, o, 64);
+    return m;
 }
 
 template <int TM, int WAVES_M, int WAVES_N, bool SPLIT = false>
@@ -98,7 +107,8 @@ __global__ __launch_bounds__(256) void k_conv128(const float* __restrict__ X, co
         s_nbr[idx] = v;
         if (v >= 0) mymask |= 1u << k;
     }
-    if (mymask) atomicOr(&s_kmask, mymask);
+    mymask = wave_or_u(mymask);  // one LDS atomic per wave (a per-lane atomicOr compiles to a serial loop over the active lanes, ~1 us)
+    if (lane == 0 && mymask) atomicOr(&s_kmask, mymask);
     __syncthreads();
     const unsigned kmask = s_kmask;
     // which offsets have a neighbour for THIS wave's rows
@@ -291,7 +301,8 @@ __global__ __launch_bounds__(NW * 64) void k_conv128_rows(const float* __restric
         if (kk < K) s_nbr[kk * TM + slot_r] = v_nbr[j];
         if (v_nbr[j] >= 0) mymask |= 1u << kk;
     }
-    if (mymask) atomicOr(&s_kmask, mymask);
+    mymask = wave_or_u(mymask);  // one LDS atomic per wave (a per-lane atomicOr compiles to a serial loop over the active lanes, ~1 us)
+    if (lane == 0 && mymask) atomicOr(&s_kmask, mymask);
     __syncthreads();
     const unsigned kmask = s_kmask;
     // (No per-wave skip of an offset none of the wave's 32 rows has: in pattern order a tile's union is 1.03x the algorithmic work, and the
@@ -670,27 +681,29 @@ struct __attribute__((packed, aligned(4))) f32x3 { float x, y, z; };
 __device__ __forceinline__ int conv3_pos(int k) { return (k % 3 == 1 ? 0 : k % 3 == 0 ? 9 : 18) + k / 3; }   // offset -> column group
 __device__ __forceinline__ int conv3_off(int p) { return (p % 9) * 3 + (p < 9 ? 1 : p < 18 ? 0 : 2); }       // column group -> offset
 
-__global__ __launch_bounds__(256) void k_conv3_fwd(const float* __restrict__ X, const float* __restrict__ W /*[K][3][128]*/, const int* __restrict__ nbr,
+__global__ __launch_bounds__(256, 3) void k_conv3_fwd(const float* __restrict__ X, const float* __restrict__ W /*[K][3][128]*/, const int* __restrict__ nbr,
                                                    int64_t ld, int K, int M_bound, const int* __restrict__ m_dev, float* __restrict__ Y) {
     constexpr int LDA = 97;
     __shared__ float As[64 * LDA];
-    __shared__ unsigned s_pmask;
+    __shared__ __align__(16) unsigned s_pm[4];  // column groups present in the tile, one word per wave (ballots: no LDS atomics)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int i32 = lane & 31, h = lane >> 5;
     const int M_out = m_dev ? min(*m_dev, M_bound) : M_bound;
     if ((int64_t)blockIdx.x * 64 >= M_out) return;
     // The wave's slice of W (96 columns x its 32 output channels) lives in REGISTERS for the whole kernel: lane (i32, h) holds exactly
     // the B operands it feeds to the 48 MFMA steps.  48 coalesced loads per lane, issued together, once per workgroup.
-    float wv[48];
+    // Columns 0..63 go in two chunks of 16 steps (lane half h takes 16 consecutive columns of a chunk); the last 17 columns (+1 of
+    // zeros) in a chunk of 9 steps, lane half h taking columns 64 + 9h ..: 41 MFMA steps per tile, not 48.
+    float wv[41];
 #pragma unroll
-    for (int t = 0; t < 48; ++t) {
-        const int j = (t >> 4) * 32 + h * 16 + (t & 15);          // column of step t for this lane half
+    for (int t = 0; t < 41; ++t) {
+        const int j = t < 32 ? (t >> 4) * 32 + h * 16 + (t & 15) : 64 + h * 9 + (t - 32);  // column of step t for this lane half
         const int wrow = conv3_off(min(j, 80) / 3) * 3 + min(j, 80) % 3;
         wv[t] = W[wrow * 128 + wid * 32 + i32];
         if (j >= 81) wv[t] = 0.f;
     }
     for (int i = tid; i < 64 * LDA; i += 256) As[i] = 0.f;  // columns 81..96 stay zero
-    const int sr = tid & 63, sk = tid >> 6;                 // staging: row of the tile, offset lane (4 lanes walk the 27 offsets)
+    const int sr = tid & 63, sk = __builtin_amdgcn_readfirstlane(tid >> 6);  // staging: row of the tile, offset lane (4 lanes walk the 27 offsets)
     // Two-stage software pipeline over the workgroup's tiles: while the matrix cores work on tile t, the gathers of tile t+1 (through the
     // table entries read one iteration ago) and the table reads of tile t+2 are in flight; nothing is waited for in the iteration
     // that issues it.
@@ -713,9 +726,8 @@ __global__ __launch_bounds__(256) void k_conv3_fwd(const float* __restrict__ X, 
     load_nb((int64_t)blockIdx.x * 64 + tstep, nb2);
     gather();
     for (int64_t row0 = (int64_t)blockIdx.x * 64; row0 < M_out; row0 += tstep) {  // persistent: tiles strided by the grid
-        if (tid == 0) s_pmask = 0;
-        lds_barrier();  // previous tile's MFMA reads of As are done; zero fill visible.  LDS-only: the output stores stay in flight
-        unsigned mymask = 0;
+        lds_barrier();  // previous tile's MFMA reads of As (and of s_pm) are done; zero fill visible.  LDS-only: the output stores stay in flight
+        unsigned wmask = 0;  // wave-uniform: the wave stages offsets wid, wid + 4, ...
         const bool live = row0 + sr < M_out;
 #pragma unroll
         for (int kk = 0; kk < 7; ++kk) {
@@ -723,19 +735,20 @@ __global__ __launch_bounds__(256) void k_conv3_fwd(const float* __restrict__ X, 
             if (k < 27) {
                 const bool ok = live && nb[kk] >= 0;
                 const int p = conv3_pos(k);
-                if (ok) mymask |= 1u << p;
+                if (__ballot(ok)) wmask |= 1u << p;
                 As[sr * LDA + p * 3 + 0] = ok ? xv[kk][0] : 0.f;
                 As[sr * LDA + p * 3 + 1] = ok ? xv[kk][1] : 0.f;
                 As[sr * LDA + p * 3 + 2] = ok ? xv[kk][2] : 0.f;
             }
         }
-        if (mymask) atomicOr(&s_pmask, mymask);
+        if (lane == 0) s_pm[wid] = wmask;
         lds_barrier();
 #pragma unroll
         for (int kk = 0; kk < 7; ++kk) nb[kk] = nb2[kk];
         gather();                          // tile t+1
         load_nb(row0 + 2 * tstep, nb2);    // tile t+2
-        const unsigned pmask = __builtin_amdgcn_readfirstlane(s_pmask);  // wave-uniform: chunk skipping is a scalar branch
+        const uint4 pm4 = *(const uint4*)s_pm;
+        const unsigned pmask = __builtin_amdgcn_readfirstlane(pm4.x | pm4.y | pm4.z | pm4.w);  // wave-uniform: chunk skipping is a scalar branch
         f32x16 acc[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -746,15 +759,21 @@ __global__ __launch_bounds__(256) void k_conv3_fwd(const float* __restrict__ X, 
             // column groups touched by chunk q: columns [32q, 32q+32) = groups [32q/3, (32q+31)/3]
             const unsigned groups = ((2u << ((q * 32 + 31) / 3)) - 1u) & ~((1u << (q * 32 / 3)) - 1u);
             if (!(pmask & groups)) continue;
-            float av[2][16];
+            const int ns = q < 2 ? 16 : 9, c0 = q * 32 + h * ns;
 #pragma unroll
-            for (int s2 = 0; s2 < 16; ++s2)
+            for (int s0 = 0; s0 < ns; s0 += 8) {  // 8 steps of operands at a time: 16 registers, three workgroups per CU
+                float av[2][8];
 #pragma unroll
-                for (int m = 0; m < 2; ++m) av[m][s2] = As[(m * 32 + i32) * LDA + q * 32 + h * 16 + s2];
+                for (int s2 = 0; s2 < 8; ++s2)
 #pragma unroll
-            for (int s2 = 0; s2 < 16; ++s2)
+                    for (int m = 0; m < 2; ++m)
+                        if (s0 + s2 < ns) av[m][s2] = As[(m * 32 + i32) * LDA + c0 + s0 + s2];
 #pragma unroll
-                for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][s2], wv[q * 16 + s2], acc[m], 0, 0, 0);
+                for (int s2 = 0; s2 < 8; ++s2)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+                        if (s0 + s2 < ns) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][s2], wv[q * 16 + s0 + s2], acc[m], 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -823,31 +842,35 @@ __global__ __launch_bounds__(256) void k_conv3_bwd_data(const float* __restrict_
 // dW[g][k][ci][co] partial per row chunk on the fp32 matrix cores: out[81 (pad 96)][128] = A^T . dY with the im2col tile
 // A[o][3 pos(k) + ci] = X[nbr[k][o]][ci] built in LDS, 32 rows at a time (same column order as k_conv3_fwd, so flat clouds only
 // ever fill the first of the three 32-column output tiles and the other two are skipped).  Wave w owns output columns
-// [32w, 32w+32).  Two-stage software pipeline: while the matrix cores work on rows rb.., the gathers of rb+32.. and the
-// neighbour-table reads of rb+64.. are in flight; even and odd MFMA steps use separate accumulators (no dependent chain).
-__global__ __launch_bounds__(256) void k_conv3_bww(const float* __restrict__ X, const float* __restrict__ dY, const int* __restrict__ nbr, int64_t ld,
-                                                   const int* __restrict__ group_row_off, int G, float* __restrict__ slabs, int* __restrict__ slab_valid) {
+// [32w, 32w+32) and reads ITS 128 bytes of every dY row straight from global memory in the MFMA operand layout (lane (i32, h) of
+// step s2 holds dY[rb + 16 h + s2][32 w + i32]: whole 128-byte lines, each read by exactly one wave) -- dY never passes through
+// LDS.  The im2col tile is double-buffered, so a 32-row step has ONE barrier; while the matrix cores work on rows rb.., the dY rows
+// and gathers of rb+32.. and the neighbour-table reads of rb+64.. are in flight.  Even and odd MFMA steps of the first output
+// tile use separate accumulators (no dependent chain).  <= 168 registers: three workgroups per CU.
+__global__ __launch_bounds__(256, 3) void k_conv3_bww(const float* __restrict__ X, const float* __restrict__ dY, const int* __restrict__ nbr, int64_t ld,
+                                                      const int* __restrict__ group_row_off, int G, float* __restrict__ slabs, int* __restrict__ slab_valid) {
     constexpr int LDA = 97;  // 96 + 1: the im2col writes walk rows (stride LDA) and must not land on one bank
-    __shared__ float As[32 * LDA];
-    __shared__ f32x4 Ds4[32 * 32];
-    __shared__ unsigned s_pmask[2];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    __shared__ float As[2][32 * LDA];
+    __shared__ __align__(16) unsigned s_pm[2][4];  // column groups present in a buffer's rows, one word per wave (ballots: no LDS atomics)
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i32 = lane & 31, h = lane >> 5;
     const int c = blockIdx.x;
+    PROF_T(pt0);
+#ifdef DD3D_CONV_PROF
+    long long sg0 = 0, sg1 = 0, sg2 = 0, sg3 = 0, n_it = 0;
+#endif
     int g, r0, r1;
     const int CH = chunk3(group_row_off[G]);
     if (!resolve_chunk(c, group_row_off, G, CH, &g, &r0, &r1)) return;
-    for (int i = tid; i < 32 * LDA; i += 256) As[i] = 0.f;  // pad columns 81..96 stay zero
-    if (tid < 2) s_pmask[tid] = 0;
+    for (int i = tid; i < 2 * 32 * LDA; i += 256) (&As[0][0])[i] = 0.f;  // pad columns 81..96 stay zero
     f32x16 acc[4];  // output tile 0 (the one flat clouds use) has two accumulators: [0] even steps, [3] odd steps
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-    const f32x4* D4 = (const f32x4*)dY;
-    const float* Ds = (const float*)Ds4;
-    const int sr = tid & 31, sk = tid >> 5;  // staging: row within the sub-block, offset lane (8 lanes walk the 27 offsets)
-    // every load is clamped to the chunk (valid address, no branch); rows beyond r1 are zeroed when they are written to LDS
+    const int sr = tid & 31, sk = tid >> 5;  // staging: row within the sub-block, offset lane (8 lanes walk the 27 offsets; sk = 2 wid + h)
+    const float* dYw = dY + wid * 32 + i32;
+    // every load is clamped to the chunk (valid address, no branch); rows beyond r1 are zeroed before they are used
     auto load_nb = [&](int rb, int* nb) {
         const int rowc = min(rb + sr, r1 - 1);
 #pragma unroll
@@ -860,70 +883,83 @@ __global__ __launch_bounds__(256) void k_conv3_bww(const float* __restrict__ X, 
             xv[kk][0] = x.x; xv[kk][1] = x.y; xv[kk][2] = x.z;
         }
     };
-    auto load_d = [&](int rb, f32x4* d) {
+    auto load_b = [&](int rb, float* b) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int idx = j * 256 + tid;
-            d[j] = D4[(int64_t)min(rb + (idx >> 5), r1 - 1) * 32 + (idx & 31)];
-        }
+        for (int s2 = 0; s2 < 16; ++s2) b[s2] = dYw[(int64_t)min(rb + h * 16 + s2, r1 - 1) * 128];
     };
-    auto store = [&](int rb, const int* nb, const float (*xv)[3], const f32x4* d, int par) {
-        unsigned mymask = 0;
+    auto store = [&](int rb, const int* nb, const float (*xv)[3], float* as, unsigned* pm) {
+        unsigned wmask = 0;  // wave-uniform
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int k = sk + kk * 8;
+            const bool ok = k < 27 && rb + sr < r1 && nb[kk] >= 0;
+            const unsigned long long bal = __ballot(ok);  // low half: offset 2 wid + 8 kk, high half: the next one
+            if ((unsigned)bal) wmask |= 1u << conv3_pos(2 * wid + kk * 8);
+            if ((unsigned)(bal >> 32)) wmask |= 1u << conv3_pos(2 * wid + 1 + kk * 8);
             if (k < 27) {
-                const bool ok = rb + sr < r1 && nb[kk] >= 0;
                 const int p = conv3_pos(k);
-                if (ok) mymask |= 1u << p;
-                As[sr * LDA + p * 3 + 0] = ok ? xv[kk][0] : 0.f;
-                As[sr * LDA + p * 3 + 1] = ok ? xv[kk][1] : 0.f;
-                As[sr * LDA + p * 3 + 2] = ok ? xv[kk][2] : 0.f;
+                as[sr * LDA + p * 3 + 0] = ok ? xv[kk][0] : 0.f;
+                as[sr * LDA + p * 3 + 1] = ok ? xv[kk][1] : 0.f;
+                as[sr * LDA + p * 3 + 2] = ok ? xv[kk][2] : 0.f;
             }
         }
-        if (mymask) atomicOr(&s_pmask[par], mymask);
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int idx = j * 256 + tid;
-            Ds4[idx] = rb + (idx >> 5) < r1 ? d[j] : zero;
-        }
+        if (lane == 0) pm[wid] = wmask;
     };
     int nbA[4], nbB[4];
     float xv[4][3];
-    f32x4 d[4];
+    float bv0[16], bv1[16];
     load_nb(r0, nbA);
     load_nb(r0 + 32, nbB);
     load_x(nbA, xv);
-    load_d(r0, d);
-    __syncthreads();  // zero fill and mask reset visible
-    store(r0, nbA, xv, d, 0);
+    load_b(r0, bv0);
+    __syncthreads();  // zero fill visible
+    store(r0, nbA, xv, As[0], s_pm[0]);
     __syncthreads();
-    int par = 0;
-    for (int rb = r0; rb < r1; rb += 32, par ^= 1) {
-        // stage 1 of rb+32 (gathers through the table entries read one iteration ago) and stage 0 of rb+64
-        load_x(nbB, xv);
-        load_d(rb + 32, d);
+    PROF_T(pt1);
+    // One 32-row step.  `bv` holds the step's dY rows (loaded one step ago), `bvn` receives the next step's; `nbx` holds the table entries of
+    // rows rb+32.. (read one step ago: their gathers go out now), `nby` receives those of rb+64...  The two calls per loop trip swap the
+    // roles, so no loaded register is ever copied (a copy would wait for the load at the end of the step that issued it).
+    auto step = [&](int rb, int par, float* bv, float* bvn, int* nbx, int* nby) {
+        PROF_T(q0);
+        const float* as = As[par];
+        load_x(nbx, xv);
+        load_b(rb + 32, bvn);
+        load_nb(rb + 64, nby);
+        const uint4 pm4 = *(const uint4*)s_pm[par];
+        const unsigned pmask = __builtin_amdgcn_readfirstlane(pm4.x | pm4.y | pm4.z | pm4.w);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) nbA[kk] = nbB[kk];
-        load_nb(rb + 64, nbB);
-        const unsigned pmask = __builtin_amdgcn_readfirstlane(s_pmask[par]);
-        if (tid == 0) s_pmask[par ^ 1] = 0;  // last read two barriers ago, next written after the barrier below
+        for (int s2 = 0; s2 < 16; ++s2)
+            if (rb + h * 16 + s2 >= r1) bv[s2] = 0.f;  // the clamped load repeated the chunk's last row
+        PROF_T(q1);
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
             const unsigned groups = ((2u << ((m * 32 + 31) / 3)) - 1u) & ~((1u << (m * 32 / 3)) - 1u);  // column groups of output tile m
             if (!(pmask & groups)) continue;
 #pragma unroll
             for (int s2 = 0; s2 < 16; ++s2) {
-                const float bv = Ds[(h * 16 + s2) * 128 + wid * 32 + i32];
-                const float av = As[(h * 16 + s2) * LDA + m * 32 + i32];
+                const float av = as[(h * 16 + s2) * LDA + m * 32 + i32];
                 const int ai = (m == 0 && (s2 & 1)) ? 3 : m;
-                acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[ai], 0, 0, 0);
+                acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[s2], acc[ai], 0, 0, 0);
             }
         }
+        PROF_T(q2);
+        if (rb + 32 < r1) store(rb + 32, nbx, xv, As[par ^ 1], s_pm[par ^ 1]);  // the other buffer: its readers passed the last barrier
+        PROF_T(q3);
         __syncthreads();
-        if (rb + 32 < r1) store(rb + 32, nbA, xv, d, par ^ 1);
-        __syncthreads();
+        PROF_T(q4);
+        PROF_ADD(sg0, q0, q1);
+        PROF_ADD(sg1, q1, q2);
+        PROF_ADD(sg2, q2, q3);
+        PROF_ADD(sg3, q3, q4);
+        PROF_ADD(n_it, 0, 1);
+    };
+    for (int rb = r0;;) {
+        step(rb, 0, bv0, bv1, nbB, nbA);
+        rb += 32;
+        if (rb >= r1) break;
+        step(rb, 1, bv1, bv0, nbA, nbB);
+        rb += 32;
+        if (rb >= r1) break;
     }
     float* slab = slabs + (int64_t)c * (81 * 128);
 #pragma unroll
@@ -934,6 +970,13 @@ __global__ __launch_bounds__(256) void k_conv3_bww(const float* __restrict__ X, 
             if (col < 81) slab[(conv3_off(col / 3) * 3 + col % 3) * 128 + wid * 32 + i32] = m == 0 ? acc[0][r] + acc[3][r] : acc[m][r];
         }
     if (tid == 0) slab_valid[c] = 1;
+#ifdef DD3D_CONV_PROF
+    if (lane == 0 && wid == 0 && c < 4096) {  // [start, end, loop start, iterations, HW_ID, XCC_ID, issue+dY wait | multiply, store | barrier]
+        long long* o = g_prof + (int64_t)c * 8;
+        o[0] = pt0, o[1] = wall_clock64(), o[2] = pt1, o[3] = n_it;
+        o[4] = __builtin_amdgcn_s_getreg(4 | (31 << 11)), o[5] = __builtin_amdgcn_s_getreg(20 | (31 << 11)), o[6] = sg0 | (sg1 << 32), o[7] = sg2 | (sg3 << 32);
+    }
+#endif
 }
 
 __global__ void k_transpose_kernel(const float* __restrict__ W, int K, int Cin, int Cout, float* __restrict__ Wt) {
