@@ -24,9 +24,15 @@ struct CloudSmem {
     // table capacity: load factor <= 0.5, so every probe sequence meets an empty slot; small clouds get 4 slots per point, which also lets
     // a 28 x 28 pixel grid (784 cells) be addressed DIRECTLY (see Cells)
     static constexpr int HC = NMAX <= 256 ? 4 * NMAX : 2 * NMAX;
+    // strides 2 and 4 hold at most NMAX keys too, but their direct grids are small (14 x 14, 7 x 7): 2 slots per key keep the load factor
+    // and leave the struct under 40 KB for NMAX = 256 -- four clouds per CU instead of three
+    static constexpr int HC2 = 2 * NMAX;
     int4 q[NMAX];                        // floored point coordinates
+    int tab1[HC], tab2[HC2], tab4[HC2];  // coordinate -> local voxel id, linear probing, -1 = empty
+    int s_w[8];
+    int box[2][6];                       // bounding boxes of the stride-1 and stride-2 voxels: lo[3], hi[3]
+    // ---- k_cloud_count uses nothing below this line: its launch allocates offsetof(U1) bytes (12 KB for NMAX = 256: ten clouds per CU)
     int4 U1[NMAX], U2[NMAX], U4[NMAX];   // unique coordinates at strides 1, 2, 4 (first-occurrence order)
-    int tab1[HC], tab2[HC], tab4[HC];    // coordinate -> local voxel id, linear probing, -1 = empty
     int tmin[HC];                        // scratch: minimum key index per slot while a table is being built
     int slot[NMAX];                      // scratch: slot of every key of the table being built
     int lid1[NMAX];                      // point -> local voxel id (stride 1)
@@ -34,8 +40,6 @@ struct CloudSmem {
     int first1[NMAX];                    // stride-1 voxel -> its first point (local index)
     int first2[NMAX], first4[NMAX];      // stride-2 voxel -> its first stride-1 voxel ; stride-4 voxel -> its first stride-2 voxel
     int cnt[NMAX + 1];                   // CSR scratch
-    int box[2][6];                       // bounding boxes of the stride-1 and stride-2 voxels: lo[3], hi[3]
-    int s_w[8];
 };
 
 __device__ __forceinline__ int4 stride_coord(int4 c, int s) {
@@ -171,7 +175,7 @@ struct CloudCounts {
 template <int NMAX>
 __device__ CloudCounts build_cloud(CloudSmem<NMAX>& S, const float4* __restrict__ coords, int p0, int n_raw, int b, int* err, int* n_out, Cells* cells1_out,
                                    Cells* cells2_out) {
-    constexpr int HC = CloudSmem<NMAX>::HC;
+    constexpr int HC = CloudSmem<NMAX>::HC, HC2 = CloudSmem<NMAX>::HC2;
     const int tid = threadIdx.x;
     int n = n_raw;
     if (n > NMAX) {
@@ -201,19 +205,19 @@ __device__ CloudCounts build_cloud(CloudSmem<NMAX>& S, const float4* __restrict_
     int box4[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) box4[j] = floor_div_i(S.box[1][j], 4) * 4;
-    const Cells cells1 = cells_of(S.box[0], 0, HC), cells2 = cells_of(S.box[1], 1, HC);
+    const Cells cells1 = cells_of(S.box[0], 0, HC), cells2 = cells_of(S.box[1], 1, HC2);
     *cells1_out = cells1;
     *cells2_out = cells2;
-    const Cells cells4 = cells_of(box4, 2, HC);
+    const Cells cells4 = cells_of(box4, 2, HC2);
     CloudCounts c;
     c.m1 = lds_unique<HC>(S.q, n, cells1, S.tab1, S.tmin, S.slot, S.U1, S.lid1, S.first1, S.s_w);
     // stride 2: keys = stride-2 coordinate of every stride-1 voxel (q is free again and serves as key storage)
     for (int v = tid; v < c.m1; v += CT) S.q[v] = stride_coord(S.U1[v], 2);
     lds_barrier();
-    c.m2 = lds_unique<HC>(S.q, c.m1, cells2, S.tab2, S.tmin, S.slot, S.U2, S.par2, S.first2, S.s_w);
+    c.m2 = lds_unique<HC2>(S.q, c.m1, cells2, S.tab2, S.tmin, S.slot, S.U2, S.par2, S.first2, S.s_w);
     for (int v = tid; v < c.m2; v += CT) S.q[v] = stride_coord(S.U2[v], 4);
     lds_barrier();
-    c.m4 = lds_unique<HC>(S.q, c.m2, cells4, S.tab4, S.tmin, S.slot, S.U4, S.par4, S.first4, S.s_w);
+    c.m4 = lds_unique<HC2>(S.q, c.m2, cells4, S.tab4, S.tmin, S.slot, S.U4, S.par4, S.first4, S.s_w);
     *n_out = n;
     return c;
 }
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(CT) void k_cloud_count(const float4* __restrict__ c
                                                     const int* __restrict__ cloud_group, int* __restrict__ cnt /*[3][B]*/, int* gmin /*[G][3]*/,
                                                     int* err, int* __restrict__ cmin /*[3][B] or null*/, int* __restrict__ vox_at /*[S][B] or null*/,
                                                     int S_sites) {
-    constexpr int HC = CloudSmem<NMAX>::HC;
+    constexpr int HC = CloudSmem<NMAX>::HC, HC2 = CloudSmem<NMAX>::HC2;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     CloudSmem<NMAX>& S = *reinterpret_cast<CloudSmem<NMAX>*>(smem_raw);
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -238,7 +242,8 @@ __global__ __launch_bounds__(CT) void k_cloud_count(const float4* __restrict__ c
         n = NMAX;
         if (tid == 0) atomicOr(err, 8);
     }
-    for (int i = tid; i < HC; i += CT) S.tab1[i] = S.tab2[i] = S.tab4[i] = -1;
+    for (int i = tid; i < HC; i += CT) S.tab1[i] = -1;
+    for (int i = tid; i < HC2; i += CT) S.tab2[i] = S.tab4[i] = -1;
     if (tid < 6) S.s_w[tid] = tid < 3 ? 0 : 0x7F7F7F7F;
     if (vox_at)  // this cloud's column of the dense table starts empty (k_cloud_emit fills it in): no memset node
         for (int s = tid; s < S_sites; s += CT) vox_at[(int64_t)s * B + b] = -1;
@@ -264,19 +269,19 @@ __global__ __launch_bounds__(CT) void k_cloud_count(const float4* __restrict__ c
             if (coord_eq(S.q[old], k1)) break;
             h = (h + 1) & (HC - 1);
         }
-        h = hash_coord(k2) & (HC - 1);
+        h = hash_coord(k2) & (HC2 - 1);
         for (;;) {
             const int old = atomicCAS(&S.tab2[h], -1, i);
             if (old == -1) { ++won2; break; }
             if (coord_eq(stride_coord(S.q[old], 2), k2)) break;
-            h = (h + 1) & (HC - 1);
+            h = (h + 1) & (HC2 - 1);
         }
-        h = hash_coord(k4) & (HC - 1);
+        h = hash_coord(k4) & (HC2 - 1);
         for (;;) {
             const int old = atomicCAS(&S.tab4[h], -1, i);
             if (old == -1) { ++won4; break; }
             if (coord_eq(stride_coord(S.q[old], 4), k4)) break;
-            h = (h + 1) & (HC - 1);
+            h = (h + 1) & (HC2 - 1);
         }
     }
     won1 = wave_sum_i(won1); won2 = wave_sum_i(won2); won4 = wave_sum_i(won4);
@@ -314,8 +319,7 @@ __global__ void k_cloud_scan(const int* __restrict__ cnt, int B, int* __restrict
                              const int* __restrict__ group_cloud_off, int G, int* __restrict__ gro /*[3][G+1] or null*/,
                              const int* __restrict__ cmin /*[3][B] or null*/, const int* __restrict__ cloud_group, int* __restrict__ gmin /*[G][3]*/,
                              const int* __restrict__ gmin_floor /*[G][3] or null*/) {
-    __shared__ int s_w[16];
-    __shared__ int s_carry;
+    __shared__ int s_w[48];
     __shared__ int s_gmin[GMIN_LDS_GROUPS * 3];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (cmin) {  // gmin[g][a] = min over the clouds of group g (G <= GMIN_LDS_GROUPS, checked by the host)
@@ -331,41 +335,51 @@ __global__ void k_cloud_scan(const int* __restrict__ cnt, int B, int* __restrict
         __syncthreads();
         for (int i = threadIdx.x; i < G * 3; i += 1024) gmin[i] = s_gmin[i];
     }
+    // One pass for the three levels: thread t takes the clouds [t per, (t + 1) per) of every level, sums them, the 1024 partial sums
+    // are scanned across the block (wave shuffles + 16 wave totals per level, ONE barrier), and the thread walks its clouds again to
+    // write their offsets (the second read hits L2).
+    const int per = (B + 1023) / 1024, b0 = min((int)threadIdx.x * per, B), b1 = min(b0 + per, B);
+    int part[3] = {0, 0, 0};
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+        for (int i = b0; i < b1; ++i) part[l] += cnt[l * B + i];
+    int incl[3];
+#pragma unroll
     for (int l = 0; l < 3; ++l) {
-        if (threadIdx.x == 0) s_carry = 0;
-        __syncthreads();
-        for (int base = 0; base < B; base += 1024) {
-            const int i = base + threadIdx.x;
-            const int v = i < B ? cnt[l * B + i] : 0;
-            int incl = v;
+        incl[l] = part[l];
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                int t = __shfl_up(incl, o, 64);
-                if (lane >= o) incl += t;
-            }
-            if (lane == 63) s_w[w] = incl;
-            __syncthreads();
-            int wbase = 0, tot = 0;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl[l], o, 64);
+            if (lane >= o) incl[l] += t;
+        }
+        if (lane == 63) s_w[l * 16 + w] = incl[l];
+    }
+    __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                int x = s_w[j];
-                if (j < w) wbase += x;
-                tot += x;
-            }
-            const int carry = s_carry;
-            if (i < B) seg[l * (B + 1) + i] = carry + wbase + incl - v;
-            __syncthreads();
-            if (threadIdx.x == 0) s_carry = carry + tot;
-            __syncthreads();
+    for (int l = 0; l < 3; ++l) {
+        int wbase = 0, tot = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int x = s_w[l * 16 + j];
+            if (j < w) wbase += x;
+            tot += x;
+        }
+        int run = wbase + incl[l] - part[l];
+        for (int i = b0; i < b1; ++i) {
+            seg[l * (B + 1) + i] = run;
+            run += cnt[l * B + i];
         }
         if (threadIdx.x == 0) {
-            seg[l * (B + 1) + B] = s_carry;
-            counts[l] = s_carry;
+            seg[l * (B + 1) + B] = tot;
+            counts[l] = tot;
         }
-        __syncthreads();
-        // first row of every group of clouds at this stride (what the per-group reductions of the feature kernels walk)
-        if (gro)
-            for (int g = threadIdx.x; g <= G; g += 1024) gro[l * (G + 1) + g] = seg[l * (B + 1) + group_cloud_off[g]];
+    }
+    if (gro) {  // first row of every group of clouds at each stride (what the per-group reductions of the feature kernels walk)
+        __syncthreads();  // the offsets written above, read back through global memory inside the workgroup
+        for (int i = threadIdx.x; i < 3 * (G + 1); i += 1024) {
+            const int l = i / (G + 1), g = i - l * (G + 1);
+            gro[i] = seg[l * (B + 1) + group_cloud_off[g]];
+        }
     }
 }
 
@@ -394,7 +408,7 @@ template <int NMAX>
 __global__ __launch_bounds__(CT) void k_cloud_emit(const float4* __restrict__ coords, const int* __restrict__ pt_off, int B,
                                                    const int* __restrict__ cloud_group, const int* __restrict__ seg /*[3][B+1]*/, CloudOut o,
                                                    int* err) {
-    constexpr int HC = CloudSmem<NMAX>::HC;
+    constexpr int HC = CloudSmem<NMAX>::HC, HC2 = CloudSmem<NMAX>::HC2;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     CloudSmem<NMAX>& S = *reinterpret_cast<CloudSmem<NMAX>*>(smem_raw);
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -477,7 +491,7 @@ __global__ __launch_bounds__(CT) void k_cloud_emit(const float4* __restrict__ co
         int d0, d1, d2;
         k3_offset(k, 2, &d0, &d1, &d2);
         const int4 u = S.U2[v];
-        const int r = lds_lookup<HC>(S.tab2, S.U2, S.box[1], cells2, make_int4(u.x, u.y + d0, u.z + d1, u.w + d2));
+        const int r = lds_lookup<HC2>(S.tab2, S.U2, S.box[1], cells2, make_int4(u.x, u.y + d0, u.z + d1, u.w + d2));
         o.nbr2[(int64_t)k * o.ld + r2 + v] = r < 0 ? -1 : r2 + r;
     }
     // k=2 pooling maps: children of a stride-2s voxel at offsets {0,1}*s, k = e0 + 2 e1 + 4 e2
@@ -490,7 +504,7 @@ __global__ __launch_bounds__(CT) void k_cloud_emit(const float4* __restrict__ co
     for (int idx = tid; idx < 8 * c.m4; idx += CT) {
         const int k = idx / c.m4, v = idx - k * c.m4;
         const int4 u = S.U4[v];
-        const int r = lds_lookup<HC>(S.tab2, S.U2, S.box[1], cells2, make_int4(u.x, u.y + 2 * (k & 1), u.z + 2 * ((k >> 1) & 1), u.w + 2 * (k >> 2)));
+        const int r = lds_lookup<HC2>(S.tab2, S.U2, S.box[1], cells2, make_int4(u.x, u.y + 2 * (k & 1), u.z + 2 * ((k >> 1) & 1), u.w + 2 * (k >> 2)));
         o.kid4[(int64_t)k * o.ld + r4 + v] = r < 0 ? -1 : r2 + r;
     }
     // dense() placement of the stride-4 voxels: site = flat index relative to the group's minimum corner
@@ -516,12 +530,13 @@ template <int NMAX>
 int launch_cloud_maps(const float4* coords, const int* pt_off, int B, const int* cloud_group, int* cnt, int* seg, int* counts, const CloudOut& o,
                       int* gmin, int* err, const int* group_cloud_off, int G, int* gro, const int* gmin_floor, hipStream_t st) {
     int* cmin = (gmin && G <= GMIN_LDS_GROUPS) ? cnt + 3 * (int64_t)B : nullptr;
-    const size_t smem = sizeof(CloudSmem<NMAX>);
+    const size_t smem = sizeof(CloudSmem<NMAX>), smem_count = offsetof(CloudSmem<NMAX>, U1);
+    static_assert(offsetof(CloudSmem<NMAX>, U1) % 16 == 0 && (NMAX > 256 || sizeof(CloudSmem<NMAX>) <= 40 * 1024), "LDS layout");
     if (smem > 64 * 1024) {
         DD3D_HIP(hipFuncSetAttribute((const void*)k_cloud_count<NMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         DD3D_HIP(hipFuncSetAttribute((const void*)k_cloud_emit<NMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     }
-    k_cloud_count<NMAX><<<dim3(B), CT, smem, st>>>(coords, pt_off, B, cloud_group, cnt, gmin, err, cmin, o.vox_at, o.E0 * o.E1 * o.E2);
+    k_cloud_count<NMAX><<<dim3(B), CT, smem_count, st>>>(coords, pt_off, B, cloud_group, cnt, gmin, err, cmin, o.vox_at, o.E0 * o.E1 * o.E2);
     k_cloud_scan<<<1, 1024, 0, st>>>(cnt, B, seg, counts, group_cloud_off, G, gro, cmin, cloud_group, gmin, gmin_floor);
     k_cloud_emit<NMAX><<<dim3(B), CT, smem, st>>>(coords, pt_off, B, cloud_group, seg, o, err);
     DD3D_CHECK_LAUNCH();

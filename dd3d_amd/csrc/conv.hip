@@ -453,9 +453,10 @@ __global__ __launch_bounds__(256) void k_offset_mask(const int* __restrict__ nbr
 #pragma unroll
         for (int k = 0; k < 27; ++k) m |= (unsigned)(k < K && v[k] >= 0) << k;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m |= __shfl_xor(m, o, 64);
-    if ((threadIdx.x & 63) == 0 && m) atomicOr(mask, m);
+    m = wave_or_u(m);
+    // bits are only ever added: a workgroup that brings nothing new (all but the first few) skips the atomic; a stale read costs a
+    // needless atomic at worst
+    if ((threadIdx.x & 63) == 0 && (m & ~__atomic_load_n(mask, __ATOMIC_RELAXED))) atomicOr(mask, m);
 }
 
 __global__ __launch_bounds__(256, 3) void k_conv128_bww(const float* __restrict__ X, const float* __restrict__ dY, const int* __restrict__ nbr, int64_t ld,
@@ -1118,7 +1119,7 @@ DD3D_API int dd3d_conv_bwd_weight(const float* X, int Cin, const float* dY, int 
         else
             {
             DD3D_HIP(hipMemsetAsync(active, 0, 4, st));
-            k_offset_mask<<<dim3(128), 256, 0, st>>>(nbr, ld, K, group_row_off, G, active);
+            k_offset_mask<<<dim3((unsigned)(ceil_div64(M_out, 256) < 1024 ? ceil_div64(M_out, 256) : 1024)), 256, 0, st>>>(nbr, ld, K, group_row_off, G, active);  // one row per thread up to 262144 rows
             k_conv128_bww<<<dim3((unsigned)(ceil_div64(slots, 8) * 8), K), 256, 0, st>>>(X, dY, nbr, ld, K, group_row_off, G, slabs, valid, active);
         }
     }
