@@ -24,8 +24,9 @@ struct CloudSmem {
     // table capacity: load factor <= 0.5, so every probe sequence meets an empty slot; small clouds get 4 slots per point, which also lets
     // a 28 x 28 pixel grid (784 cells) be addressed DIRECTLY (see Cells)
     static constexpr int HC = NMAX <= 256 ? 4 * NMAX : 2 * NMAX;
-    // strides 2 and 4 hold at most NMAX keys too, but their direct grids are small (14 x 14, 7 x 7): 2 slots per key keep the load factor
-    // and leave the struct under 40 KB for NMAX = 256 -- four clouds per CU instead of three
+    // strides 2 and 4 hold at most NMAX keys too, but their direct grids are small (14 x 14, 7 x 7): 2 slots per key keep the load factor.
+    // With that, no separate minimum-index table (a slot keeps the smallest index of its key itself) and the two scratch arrays folded
+    // into arrays that are idle at the time, the struct is 31.1 KB for NMAX = 256: five clouds per CU (it was 41 KB: three)
     static constexpr int HC2 = 2 * NMAX;
     int4 q[NMAX];                        // floored point coordinates
     int tab1[HC], tab2[HC2], tab4[HC2];  // coordinate -> local voxel id, linear probing, -1 = empty
@@ -33,13 +34,11 @@ struct CloudSmem {
     int box[2][6];                       // bounding boxes of the stride-1 and stride-2 voxels: lo[3], hi[3]
     // ---- k_cloud_count uses nothing below this line: its launch allocates offsetof(U1) bytes (12 KB for NMAX = 256: ten clouds per CU)
     int4 U1[NMAX], U2[NMAX], U4[NMAX];   // unique coordinates at strides 1, 2, 4 (first-occurrence order)
-    int tmin[HC];                        // scratch: minimum key index per slot while a table is being built
-    int slot[NMAX];                      // scratch: slot of every key of the table being built
     int lid1[NMAX];                      // point -> local voxel id (stride 1)
     int par2[NMAX], par4[NMAX];          // stride-1 voxel -> stride-2 voxel ; stride-2 voxel -> stride-4 voxel (local ids)
     int first1[NMAX];                    // stride-1 voxel -> its first point (local index)
     int first2[NMAX], first4[NMAX];      // stride-2 voxel -> its first stride-1 voxel ; stride-4 voxel -> its first stride-2 voxel
-    int cnt[NMAX + 1];                   // CSR scratch
+    int cnt[NMAX + 1];                   // CSR scratch; before that, while the tables are built: slot of every key (lds_unique)
 };
 
 __device__ __forceinline__ int4 stride_coord(int4 c, int s) {
@@ -90,30 +89,34 @@ __device__ __forceinline__ int cell_of(const Cells& c, int4 key) {  // key insid
 
 // Unique keys[0..n) in first-occurrence order -> U[0..count); tab maps a coordinate to its index in U afterwards;
 // lid[i] = index in U of keys[i]; first_idx[r] (nullable) = smallest i with keys[i] == U[r].  Returns count (block-uniform).
+// While the keys are inserted a slot holds an INDEX of its key -- the claimer's at first, then the smallest among the duplicates
+// (atomicMin; every value a slot ever holds indexes the same key, so concurrent probes compare against the right coordinate).
+// `slot` is scratch for n ints.
 template <int HC>
-__device__ int lds_unique(const int4* keys, int n, const Cells cells, int* tab, int* tmin, int* slot, int4* U, int* lid, int* first_idx, int* s_w) {
+__device__ int lds_unique(const int4* keys, int n, const Cells cells, int* tab, int* slot, int4* U, int* lid, int* first_idx, int* s_w) {
     const int tid = threadIdx.x;
-    for (int i = tid; i < HC; i += CT) {
-        tab[i] = -1;
-        tmin[i] = 0x7FFFFFFF;
-    }
+    for (int i = tid; i < HC; i += CT) tab[i] = -1;
     lds_barrier();
     for (int i = tid; i < n; i += CT) {
         const int4 key = keys[i];
         uint32_t h = cells.direct ? (uint32_t)cell_of(cells, key) : hash_coord(key) & (HC - 1);
         for (;;) {  // direct cells: the first slot is the key's own (empty, or a duplicate of the key)
-            int old = atomicCAS(&tab[h], -1, i);
-            if (old == -1 || coord_eq(keys[old], key)) break;
+            const int old = atomicCAS(&tab[h], -1, i);
+            if (old == -1) break;
+            if (coord_eq(keys[old], key)) {
+                atomicMin(&tab[h], i);  // winner among duplicates = first occurrence
+                break;
+            }
             h = (h + 1) & (HC - 1);
         }
         slot[i] = (int)h;
-        atomicMin(&tmin[h], i);  // winner among duplicates = first occurrence
     }
     lds_barrier();
     int base = 0;
     for (int c0 = 0; c0 < n; c0 += CT) {  // stable compaction of the winners, 256 keys at a time
         const int i = c0 + tid;
-        const bool first = i < n && tmin[slot[i]] == i;
+        // (a slot rewritten by an earlier round holds a voxel id r < c0 <= i, under a tag or not: never i)
+        const bool first = i < n && tab[slot[i]] == i;
         int tot;
         const int ex = block_scan(first ? 1 : 0, &tot, s_w);
         if (first) {
@@ -121,7 +124,7 @@ __device__ int lds_unique(const int4* keys, int n, const Cells cells, int* tab, 
             const int4 key = keys[i];
             U[r] = key;
             if (first_idx) first_idx[r] = i;
-            // all inserts are done: the slot now holds the voxel id (low 10 bits; NMAX <= 1024) under 21 bits of the key's hash, so a
+            // the slot now holds the voxel id (low 10 bits; NMAX <= 1024) under 21 bits of the key's hash, so a
             // hashed lookup rejects a foreign slot from the one word it has already read; keys live in U
             tab[slot[i]] = cells.direct ? r : (int)(((hash_coord(key) >> 11) & 0x1FFFFFu) << 10) | r;
         }
@@ -210,14 +213,14 @@ __device__ CloudCounts build_cloud(CloudSmem<NMAX>& S, const float4* __restrict_
     *cells2_out = cells2;
     const Cells cells4 = cells_of(box4, 2, HC2);
     CloudCounts c;
-    c.m1 = lds_unique<HC>(S.q, n, cells1, S.tab1, S.tmin, S.slot, S.U1, S.lid1, S.first1, S.s_w);
+    c.m1 = lds_unique<HC>(S.q, n, cells1, S.tab1, S.cnt, S.U1, S.lid1, S.first1, S.s_w);
     // stride 2: keys = stride-2 coordinate of every stride-1 voxel (q is free again and serves as key storage)
     for (int v = tid; v < c.m1; v += CT) S.q[v] = stride_coord(S.U1[v], 2);
     lds_barrier();
-    c.m2 = lds_unique<HC2>(S.q, c.m1, cells2, S.tab2, S.tmin, S.slot, S.U2, S.par2, S.first2, S.s_w);
+    c.m2 = lds_unique<HC2>(S.q, c.m1, cells2, S.tab2, S.cnt, S.U2, S.par2, S.first2, S.s_w);
     for (int v = tid; v < c.m2; v += CT) S.q[v] = stride_coord(S.U2[v], 4);
     lds_barrier();
-    c.m4 = lds_unique<HC2>(S.q, c.m2, cells4, S.tab4, S.tmin, S.slot, S.U4, S.par4, S.first4, S.s_w);
+    c.m4 = lds_unique<HC2>(S.q, c.m2, cells4, S.tab4, S.cnt, S.U4, S.par4, S.first4, S.s_w);
     *n_out = n;
     return c;
 }
@@ -430,7 +433,8 @@ __global__ __launch_bounds__(CT) void k_cloud_emit(const float4* __restrict__ co
     lds_barrier();
     for (int i = tid; i < n; i += CT) atomicAdd(&S.cnt[S.lid1[i]], 1);
     lds_barrier();
-    {   // exclusive scan of cnt[0..m1) in place, 256 at a time; S.slot becomes the write cursor
+    int* cursor = S.tab4;  // the stride-4 table is not looked up after build_cloud: NMAX write cursors fit in its 2 NMAX slots
+    {   // exclusive scan of cnt[0..m1) in place, 256 at a time
         int carry = 0;
         for (int c0 = 0; c0 < c.m1; c0 += CT) {
             const int v = c0 + tid;
@@ -439,7 +443,7 @@ __global__ __launch_bounds__(CT) void k_cloud_emit(const float4* __restrict__ co
             const int ex = block_scan(x, &tot, S.s_w);
             if (v < c.m1) {
                 S.cnt[v] = carry + ex;
-                S.slot[v] = 0;
+                cursor[v] = 0;
             }
             carry += tot;
         }
@@ -451,7 +455,7 @@ __global__ __launch_bounds__(CT) void k_cloud_emit(const float4* __restrict__ co
     int* lpts = reinterpret_cast<int*>(S.q);       // q is free: local point lists
     for (int i = tid; i < n; i += CT) {
         const int v = S.lid1[i];
-        lpts[S.cnt[v] + atomicAdd(&S.slot[v], 1)] = i;
+        lpts[S.cnt[v] + atomicAdd(&cursor[v], 1)] = i;
     }
     lds_barrier();
     for (int v = tid; v < c.m1; v += CT) {
@@ -531,7 +535,7 @@ int launch_cloud_maps(const float4* coords, const int* pt_off, int B, const int*
                       int* gmin, int* err, const int* group_cloud_off, int G, int* gro, const int* gmin_floor, hipStream_t st) {
     int* cmin = (gmin && G <= GMIN_LDS_GROUPS) ? cnt + 3 * (int64_t)B : nullptr;
     const size_t smem = sizeof(CloudSmem<NMAX>), smem_count = offsetof(CloudSmem<NMAX>, U1);
-    static_assert(offsetof(CloudSmem<NMAX>, U1) % 16 == 0 && (NMAX > 256 || sizeof(CloudSmem<NMAX>) <= 40 * 1024), "LDS layout");
+    static_assert(offsetof(CloudSmem<NMAX>, U1) % 16 == 0 && (NMAX > 256 || sizeof(CloudSmem<NMAX>) <= 32 * 1024), "LDS layout");
     if (smem > 64 * 1024) {
         DD3D_HIP(hipFuncSetAttribute((const void*)k_cloud_count<NMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         DD3D_HIP(hipFuncSetAttribute((const void*)k_cloud_emit<NMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
