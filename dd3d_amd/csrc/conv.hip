@@ -802,23 +802,34 @@ __global__ __launch_bounds__(256) void k_conv3_bwd_data(const float* __restrict_
     const int c4 = tid & 31, rl = tid >> 5;
     const int64_t row0 = (int64_t)blockIdx.x * rows_per_block;
     const f32x4* D4 = (const f32x4*)dY;
+    // A half-wave takes a row: lane c4 < 27 holds the row's neighbour at (mirrored) offset c4.  Only the offsets that EXIST are visited
+    // (7 of 27 on average, at most 9 for flat clouds), nine at a time, their gathers issued together: one round trip per row for flat
+    // clouds instead of nine.  Ascending offsets, present ones only: the sums are the same bits as a loop over all 27.
+    auto load_nb = [&](int it) {
+        const int64_t row = row0 + it + rl;
+        return (it < rows_per_block && row < M && c4 < K) ? nbr[(int64_t)(K - 1 - c4) * ld + row] : -1;
+    };
+    int mynb = load_nb(0);
     for (int it = 0; it < rows_per_block; it += 8) {
-        int64_t row = row0 + it + rl;
-        bool live = row < M;
-        int mynb = (live && c4 < K) ? nbr[(int64_t)(K - 1 - c4) * ld + row] : -1;
+        const int64_t row = row0 + it + rl;
+        const bool live = row < M;
+        const int nbn = load_nb(it + 8);  // the next row's table entries are in flight under this row's gathers
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-        for (int k0 = 0; k0 < 27; k0 += 3) {
-            int nb[3];
-            f32x4 d[3];
+        unsigned hm = (unsigned)(__ballot(mynb >= 0) >> (tid & 32));  // this half-wave's offsets
+        while (hm) {
+            int ks[9];
+            f32x4 d[9];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                nb[j] = __shfl(mynb, k0 + j, 32);
-                d[j] = D4[(int64_t)max(nb[j], 0) * 32 + c4];
+            for (int j = 0; j < 9; ++j) {
+                ks[j] = hm ? __ffs(hm) - 1 : -1;
+                hm &= hm - 1;  // (0 stays 0)
+                const int nb = __shfl(mynb, max(ks[j], 0), 32);
+                d[j] = D4[(int64_t)max(nb, 0) * 32 + c4];
             }
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                if (nb[j] >= 0) {  // accumulation order = ascending k, as before
-                    const int k = k0 + j;
+            for (int j = 0; j < 9; ++j) {
+                if (ks[j] >= 0) {
+                    const int k = ks[j];
                     const f32x4 w0 = Ws4[(k * 3 + 0) * 32 + c4], w1 = Ws4[(k * 3 + 1) * 32 + c4], w2 = Ws4[(k * 3 + 2) * 32 + c4];
                     s0 += d[j][0] * w0[0] + d[j][1] * w0[1] + d[j][2] * w0[2] + d[j][3] * w0[3];
                     s1 += d[j][0] * w1[0] + d[j][1] * w1[1] + d[j][2] * w1[2] + d[j][3] * w1[3];
@@ -837,6 +848,7 @@ __global__ __launch_bounds__(256) void k_conv3_bwd_data(const float* __restrict_
             dX[row * 3 + 1] = s1;
             dX[row * 3 + 2] = s2;
         }
+        mynb = nbn;
     }
 }
 
@@ -1092,7 +1104,9 @@ DD3D_API int dd3d_conv_bwd_data(const float* dY, int64_t M, const int32_t* m_dev
     if (M < 0 || K != 27 || ld < M || Cout != 128 || Cin != 3) return DD3D_EARG;
     if (M == 0) return 0;
     if (!dY || !W_or_Wt || !nbr || !dX) return DD3D_EARG;
-    const int rpb = M <= 8 * 8192 ? 8 : 64;  // one pass per workgroup while the grid stays small
+    // every workgroup stages the 41-KB kernel in LDS first: rows per workgroup sized so that one round of workgroups (~768 slots) covers the launch
+    int rpb = (int)((M / 768 + 7) / 8 * 8);
+    rpb = rpb < 8 ? 8 : rpb > 64 ? 64 : rpb;
     k_conv3_bwd_data<<<dim3((unsigned)ceil_div64(M, rpb)), 256, 0, (hipStream_t)stream>>>(dY, W_or_Wt, nbr, ld, K, (int)M, m_dev, rpb, dX);
     DD3D_CHECK_LAUNCH();
     return 0;

@@ -44,6 +44,7 @@ gw_w, gw_b = torch.empty(G, 128, device=dev), torch.empty(G, 128, device=dev)
 st = L.stream()
 ws = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
 nbr_tmp = torch.empty_like(k0)
+dF0 = torch.empty(M0, 3, device=dev)
 lv1, lv2 = cm.levels[1], cm.levels[2]
 
 K = {
@@ -63,6 +64,7 @@ K = {
                                      L.ptr(cg), L.ptr(gco), G, L.ptr(gY1), None, 0, None, None, L.ptr(gw_w), L.ptr(gw_b), L.ptr(ws), ws.numel(), st), 1024 * M1 + 1024 * M2),
  "conv128_bww": (lambda: L.call("dd3d_conv_bwd_weight", L.ptr(P0), 128, L.ptr(gY1), 128, L.ptr(k1), ld1, 27, M1, L.ptr(gro2), G, L.ptr(dW1), L.ptr(ws), ws.numel(), st), 0),
  "conv128_bww_clouds": (lambda: L.call("dd3d_conv128_bwd_weight_clouds", L.ptr(P0), L.ptr(gY1), L.ptr(k1), ld1, 27, M1, L.ptr(seg2), B, L.ptr(gro2), G, L.ptr(dW1), L.ptr(cm.err), L.ptr(ws), ws.numel(), st), 0),
+ "conv3_bwd_data (21.6k rows)": (lambda: L.call("dd3d_conv_bwd_data", L.ptr(gY0), 21600, None, 128, L.ptr(W0), 3, L.ptr(k0), ld0, 27, L.ptr(dF0), st), 21600 * (512 + 12 + 108)),
  "conv3_bww": (lambda: L.call("dd3d_conv_bwd_weight", L.ptr(F0), 3, L.ptr(gY0), 128, L.ptr(k0), ld0, 27, M0, L.ptr(gro1), G, L.ptr(dW0), L.ptr(ws), ws.numel(), st), 512 * M0 + 120 * M0),
 }
 from dd3d_amd.sparse import CloudCoordinateManager
