@@ -217,16 +217,26 @@ class _Pass:
         # The parameter gradients of the classifier and of the 128-channel convolution feed nothing but the matching loss, so they run
         # on a side stream next to the data-gradient chain (sparse linear -> pool/norm -> convolution bwd-data -> pool/norm).
         main, side = torch.cuda.current_stream(dev), self.side
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            if self.dl_scale is not None:   # (the bias gradient of the SCALED logit gradients)
-                L.call("dd3d_group_sum_rows", L.ptr(dl), L.ptr(group_cloud_off), G, J, L.ptr(g_cb), L.stream())
-            g_cw = _empty((G, J, 128 * S), dev)
-            pst = (ctypes.c_int64 * 4)(J * 128 * S, 128 * S, S, 1)
-            L.call("dd3d_sparse_linear_bwd_w", L.ptr(dl), L.ptr(P1), L.ptr(dp.vox_at), S, B, L.ptr(group_cloud_off), G, 128, J, L.ptr(g_cw), pst,
-                   g_cw.numel(), L.stream())
-            self.ev_cls = torch.cuda.Event()
-            self.ev_cls.record(side)
+
+        def classifier_gradients():
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                if self.dl_scale is not None:   # (the bias gradient of the SCALED logit gradients)
+                    L.call("dd3d_group_sum_rows", L.ptr(dl), L.ptr(group_cloud_off), G, J, L.ptr(g_cb), L.stream())
+                g_cw = _empty((G, J, 128 * S), dev)
+                pst = (ctypes.c_int64 * 4)(J * 128 * S, 128 * S, S, 1)
+                L.call("dd3d_sparse_linear_bwd_w", L.ptr(dl), L.ptr(P1), L.ptr(dp.vox_at), S, B, L.ptr(group_cloud_off), G, 128, J, L.ptr(g_cw), pst,
+                       g_cw.numel(), L.stream())
+                self.ev_cls = torch.cuda.Event()
+                self.ev_cls.record(side)
+            return g_cw
+
+        # The classifier's kernel gradient is bandwidth-bound and nothing needs it before the matching loss: started here it shares the
+        # memory system with the norm / pool backward below (both take twice their time); started behind that (DD3D_CLSW_LATE, default)
+        # it runs next to the matrix-bound input gradient of the convolution instead.
+        cls_late = os.environ.get("DD3D_CLSW_LATE", "1") != "0"
+        if not cls_late:
+            g_cw = classifier_gradients()
         gP1 = _empty((M2, 128), dev)
         sl_bwd_x_call(dl, dp, None, Wsm, sst, J, 0, gP1)
         # the ReLU-masked pooled gradients (ga) are kept for the synthetic clouds only: the second-order pass needs nothing else
@@ -238,6 +248,8 @@ class _Pass:
         # for it) and its kernel gradient (side stream, only the loss value waits for it).  Side by side they share the pipe and BOTH take
         # ~400 us; with the kernel gradient held back until the input gradient is done (DD3D_BWW_AFTER, default) the main stream gets the
         # pipe for ~200 us and the kernel gradient then overlaps the bandwidth-bound norm / pool backward and the second-order pass.
+        if cls_late:
+            g_cw = classifier_gradients()
         after = os.environ.get("DD3D_BWW_AFTER", "1") != "0"
         g_W1 = g_W0 = None
         if not after and not defer:
