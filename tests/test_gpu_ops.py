@@ -164,6 +164,27 @@ def test_conv_forward_backward(case, Cin):
     assert rel_err(w.grad, wr.grad) < 2e-5
 
 
+def test_first_layer_conv_on_dense_cubes_every_offset_present():
+    """Cin = 3 kernels where rows have far more than nine neighbours (filled 6^3 cubes: 19 of 27 on average, all 27 inside): the forward kernel's last 9-step chunk (im2col columns
+    64..80), all three output tiles of the kernel gradient and the input gradient's second and third batch of nine offsets carry real
+    data (stroke digits and sparse clouds leave them almost empty).  Against the fp64 reference, tolerance as everywhere."""
+    from dd3d_amd.ops import SparseConvFn
+    cm, M, nbr, ld, X, W = _conv_case(dict(B=3, pts=3000, extent=6, seed=11, dims3=True), 3)
+    assert float((nbr[:, :M] >= 0).sum()) / M > 12  # neighbours per row
+    x = X.to(dev()).requires_grad_()
+    w = W.to(dev()).requires_grad_()
+    Y = SparseConvFn.apply(x, w, nbr, ld, M)
+    ref_nbr = ME.kernel_map(cm.coordinates(1).cpu(), cm.coordinates(1).cpu(), 3, 1)
+    xr, wr = X.double().requires_grad_(), W.double().requires_grad_()
+    Yr = ME.SparseConvFn.apply(xr, wr, ref_nbr)
+    assert rel_err(Y, Yr) < 2e-5
+    gy = torch.randn(Yr.shape, generator=torch.Generator().manual_seed(3), dtype=torch.float64)
+    (Yr * gy).sum().backward()
+    (Y * gy.float().to(dev())).sum().backward()
+    assert rel_err(x.grad, xr.grad) < 2e-5
+    assert rel_err(w.grad, wr.grad) < 2e-5
+
+
 def test_conv_bwd_weight_grouped_and_deterministic():
     from dd3d_amd.ops import conv_bwd_weight
     cm, M, nbr, ld, X, W = _conv_case(dict(B=40, pts=300, extent=28, seed=4), 128)
