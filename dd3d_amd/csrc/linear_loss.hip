@@ -351,6 +351,7 @@ __global__ void k_softmax_ce_bwd2(const float* __restrict__ prob, const float* _
 // ---- gradient distance ------------------------------------------------------------------------------------------
 constexpr int GD_ROW_CHUNK = 8192;  // elements of one contiguous row per work item
 constexpr int GD_COL_CHUNK = 64;    // logical columns per work item in column-major segments (128 rows per item)
+constexpr int GD_U = 8;             // elements of a thread whose loads are in flight together
 
 struct GPlan {
     int n, metric;
@@ -386,9 +387,21 @@ __global__ __launch_bounds__(256) void k_gd_stats(const GPlan p, float4* __restr
         const float* a = sg.syn + row * sg.cols;
         const float* b = sg.real + row * sg.cols;
         float dot = 0.f, ss = 0.f, rr = 0.f, sq = 0.f;
-        for (int64_t e = e0 + tid; e < e1; e += 256) {
-            float x = a[e], y = b[e], d = x - y;
-            dot += x * y; ss += x * x; rr += y * y; sq += d * d;
+        // GD_U elements of the thread at a time, their loads issued together (one element per iteration left the loop a chain of 32
+        // dependent round trips: the compiler does not unroll it).  Same order of additions; the padding adds +0.
+        for (int64_t e = e0 + tid; e < e1; e += 256 * GD_U) {
+            float x[GD_U], y[GD_U];
+#pragma unroll
+            for (int j = 0; j < GD_U; ++j) {
+                const int64_t ej = e + 256 * j, ec = min(ej, e1 - 1);
+                x[j] = a[ec]; y[j] = b[ec];
+                if (ej >= e1) x[j] = y[j] = 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < GD_U; ++j) {
+                const float d = x[j] - y[j];
+                dot += x[j] * y[j]; ss += x[j] * x[j]; rr += y[j] * y[j]; sq += d * d;
+            }
         }
         dot = wave_sum(dot); ss = wave_sum(ss); rr = wave_sum(rr); sq = wave_sum(sq);
         if ((tid & 63) == 0) {
@@ -411,9 +424,19 @@ __global__ __launch_bounds__(256) void k_gd_stats(const GPlan p, float4* __restr
         int64_t q0 = (int64_t)ch * GD_COL_CHUNK, q1 = min(q0 + GD_COL_CHUNK, sg.cols);
         float dot = 0.f, ss = 0.f, rr = 0.f, sq = 0.f;
         if (r < sg.rows)
-            for (int64_t q = q0 + half; q < q1; q += 2) {
-                float x = sg.syn[q * sg.rows + r], y = sg.real[q * sg.rows + r], d = x - y;
-                dot += x * y; ss += x * x; rr += y * y; sq += d * d;
+            for (int64_t q = q0 + half; q < q1; q += 2 * GD_U) {
+                float x[GD_U], y[GD_U];
+#pragma unroll
+                for (int j = 0; j < GD_U; ++j) {
+                    const int64_t qj = q + 2 * j, qc = min(qj, q1 - 1);
+                    x[j] = sg.syn[qc * sg.rows + r]; y[j] = sg.real[qc * sg.rows + r];
+                    if (qj >= q1) x[j] = y[j] = 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < GD_U; ++j) {
+                    const float d = x[j] - y[j];
+                    dot += x[j] * y[j]; ss += x[j] * x[j]; rr += y[j] * y[j]; sq += d * d;
+                }
             }
         if (half == 1) s_half[tid & 127] = make_float4(dot, ss, rr, sq);
         __syncthreads();
@@ -526,9 +549,16 @@ __global__ __launch_bounds__(256) void k_gd_bwd(const GPlan p, const float4* __r
         float ca = 0.f, cb = 0.f;
         if (metric == 0) coef(stats[p.row_off[s] + row], &ca, &cb);
         else if (metric == 3) coef(stats[total_rows], &ca, &cb);
-        for (int64_t e = e0 + tid; e < e1; e += 256) {
-            float x = a[e], y = b[e];
-            d[e] = (metric == 1 || metric == 2) ? 2.0f * up * (x - y) : ca * y + cb * x;
+        for (int64_t e = e0 + tid; e < e1; e += 256 * GD_U) {
+            float x[GD_U], y[GD_U];
+#pragma unroll
+            for (int j = 0; j < GD_U; ++j) {
+                const int64_t ec = min(e + 256 * j, e1 - 1);
+                x[j] = a[ec]; y[j] = b[ec];
+            }
+#pragma unroll
+            for (int j = 0; j < GD_U; ++j)
+                if (e + 256 * j < e1) d[e + 256 * j] = (metric == 1 || metric == 2) ? 2.0f * up * (x[j] - y[j]) : ca * y[j] + cb * x[j];
         }
     } else {
         int rtile = local / nch, ch = local - rtile * nch;
@@ -538,10 +568,16 @@ __global__ __launch_bounds__(256) void k_gd_bwd(const GPlan p, const float4* __r
         float ca = 0.f, cb = 0.f;
         if (metric == 0) coef(stats[p.row_off[s] + r], &ca, &cb);
         else if (metric == 3) coef(stats[total_rows], &ca, &cb);
-        for (int64_t q = q0 + half; q < q1; q += 2) {
-            int64_t e = q * sg.rows + r;
-            float x = sg.syn[e], y = sg.real[e];
-            sg.dsyn[e] = (metric == 1 || metric == 2) ? 2.0f * up * (x - y) : ca * y + cb * x;
+        for (int64_t q = q0 + half; q < q1; q += 2 * GD_U) {
+            float x[GD_U], y[GD_U];
+#pragma unroll
+            for (int j = 0; j < GD_U; ++j) {
+                const int64_t ec = min(q + 2 * j, q1 - 1) * sg.rows + r;
+                x[j] = sg.syn[ec]; y[j] = sg.real[ec];
+            }
+#pragma unroll
+            for (int j = 0; j < GD_U; ++j)
+                if (q + 2 * j < q1) sg.dsyn[(q + 2 * j) * sg.rows + r] = (metric == 1 || metric == 2) ? 2.0f * up * (x[j] - y[j]) : ca * y[j] + cb * x[j];
         }
     }
 }
