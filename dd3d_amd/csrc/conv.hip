@@ -650,20 +650,21 @@ __global__ __launch_bounds__(256) void k_slab_reduce(const f32x4* __restrict__ s
 #pragma unroll 4
         for (int c = first + sl; c < first + n; c += 4) s += slabs[((int64_t)c * K + k) * elems4 + ec];
     } else {     // most (chunk, offset) slabs of flat clouds do not exist: never touch those
-        int c = first + sl;
-        for (; c + 12 < first + n; c += 16) {  // four of this lane's slots in flight (flags, then the slabs that exist), added in slot order
-            int ok[4];
-            f32x4 x[4];
+        for (int c = first + sl; c < first + n; c += 32) {  // eight of this lane's slots in flight (flags, then the slabs that exist), added in slot order
+            int ok[8];
+            f32x4 x[8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) ok[q] = slab_valid[(int64_t)(c + 4 * q) * K + k];
+            for (int q = 0; q < 8; ++q) {
+                const int cq = c + 4 * q;
+                ok[q] = slab_valid[(int64_t)min(cq, first + n - 1) * K + k];
+                if (cq >= first + n) ok[q] = 0;
+            }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) x[q] = ok[q] ? slabs[((int64_t)(c + 4 * q) * K + k) * elems4 + ec] : zero;
+            for (int q = 0; q < 8; ++q) x[q] = ok[q] ? slabs[((int64_t)(c + 4 * q) * K + k) * elems4 + ec] : zero;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 8; ++q)
                 if (ok[q]) s += x[q];
         }
-        for (; c < first + n; c += 4)
-            if (slab_valid[(int64_t)c * K + k]) s += slabs[((int64_t)c * K + k) * elems4 + ec];
     }
     s_red[threadIdx.x] = s;
     __syncthreads();

@@ -518,14 +518,14 @@ __global__ __launch_bounds__(256) void k_cloud_group_sum(const f32x4* __restrict
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     int b = group_cloud_off[g] + sl;
     const int b1 = group_cloud_off[g + 1];
-    for (; b + 48 < b1; b += 64) {  // four of this lane's clouds in flight, added in cloud order
-        f32x4 x[4];
+    for (; b < b1; b += 16 * 8) {  // eight of this lane's clouds in flight (clamped index, no branch around the loads), added in cloud order
+        f32x4 x[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) x[q] = part[((int64_t)(b + 16 * q) * 2 + j) * 32 + c4];
+        for (int q = 0; q < 8; ++q) x[q] = part[((int64_t)min(b + 16 * q, b1 - 1) * 2 + j) * 32 + c4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) s += x[q];
+        for (int q = 0; q < 8; ++q)
+            if (b + 16 * q < b1) s += x[q];
     }
-    for (; b < b1; b += 16) s += part[((int64_t)b * 2 + j) * 32 + c4];
     s_red[threadIdx.x] = s;
     __syncthreads();
     if (sl == 0) {
