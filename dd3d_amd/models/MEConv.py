@@ -1,5 +1,6 @@
-"""Drop-in for the hot-path classes of the reference's ``models/MEConv.py``: MEConvExp (:208-258), MEPytorch (:166-207) and
-create_input_batch (:260-269), on hand-written gfx950 kernels instead of MinkowskiEngine.
+"""Drop-in for the classes of the reference's ``models/MEConv.py``: MEConvExp (:208-258), MEPytorch (:166-207) and
+create_input_batch (:260-269) -- the hot path -- and the unused MEConv / MEConvImage (:10-164), on hand-written gfx950 kernels
+instead of MinkowskiEngine.
 
 Same constructor signatures, module tree (``features.{0,1,4,5}``, ``classifier``), parameter order, state_dict keys and
 initialisation as the reference.  Keyword-only extensions with reference defaults (``num_classes=10, dense_extent=(1,28,28)``)
@@ -69,6 +70,128 @@ class MEConvExp(ME.MinkowskiNetwork):
                                         ops._single_group(M_in, f.device), 1)
             ts *= 2
         return ops.sparse_linear(f, self.classifier.weight, self.classifier.bias, dp)
+
+
+class _UnusedVariant(ME.MinkowskiNetwork):
+    """Shared body of the reference's two UNUSED models (models/MEConv.py:10-164; nothing in mnist_distill.py builds them): layer
+    stacks with MinkowskiAvgPooling, and either a dense Linear head or, with ``full_minkowski=True``, MinkowskiGlobalAvgPooling +
+    MinkowskiLinear(128, 10).  Constructors, module trees, parameter names and initialisation follow the reference line by line --
+    including what does not work there: ``MEConv`` never defines ``dense_shape`` (its dense head raises AttributeError, :76) and its
+    full-Minkowski head feeds 16 channels into Linear(128, 10) (:21,81-82); ``MEConvImage``'s dense head asks ``dense()`` for one
+    channel of a 128-channel tensor (:152-156).  The one configuration that runs in the reference, MEConvImage(full_minkowski=True),
+    runs here on the HIP kernels (convolutions, instance norm, average pooling, global average pooling)."""
+
+    def _make_layers(self, in_channel, out_channel, embedding_channel):
+        layers = []
+        layers += [ME.MinkowskiConvolution(in_channel, 128, kernel_size=3, dimension=self.D)]
+        layers += [ME.MinkowskiInstanceNorm(128)]
+        layers += [ME.MinkowskiReLU(inplace=True)]
+        layers += [ME.MinkowskiAvgPooling(kernel_size=2, stride=2, dimension=self.D)]
+        in_channel = 128
+        out_channel = 64
+        for d in range(3):
+            layers += [ME.MinkowskiConvolution(in_channel, out_channel, kernel_size=3, dimension=self.D)]
+            layers += [ME.MinkowskiInstanceNorm(out_channel)]
+            layers += [ME.MinkowskiReLU(inplace=True)]
+            layers += [ME.MinkowskiAvgPooling(kernel_size=2, stride=2, dimension=self.D)]
+            in_channel //= 2
+            out_channel //= 2
+        if not self.full_minkowski:
+            layers += [ME.MinkowskiConvolution(out_channel * 2, 1, kernel_size=1, dimension=self.D)]
+        return nn.Sequential(*layers)
+
+    def weight_initialization(self):
+        for m in self.modules():
+            if isinstance(m, ME.MinkowskiLinear):
+                ME.kaiming_normal_(m.kernel, mode="fan_out", nonlinearity="relu")   # (as in the reference: MinkowskiLinear has no .kernel)
+            if isinstance(m, ME.MinkowskiConvolution):
+                ME.kaiming_normal_(m.kernel, mode="fan_out", nonlinearity="relu")
+            if isinstance(m, ME.MinkowskiBatchNorm):
+                nn.init.constant_(m.bn.weight, 1)
+                nn.init.constant_(m.bn.bias, 0)
+
+
+class MEConv(_UnusedVariant):
+    """models/MEConv.py:10-84."""
+
+    def __init__(self, in_channel, out_channel, embedding_channel=1024, dimension=3, full_minkowski=False):
+        super().__init__(dimension)
+        self.full_minkowski = full_minkowski
+        self.features = self._make_layers(1, out_channel, embedding_channel)
+        if not full_minkowski:
+            self.classifier = nn.Linear(4500, 10)
+        if full_minkowski:
+            self.global_avg_pool = ME.MinkowskiGlobalAvgPooling()
+            self.classifier = ME.MinkowskiLinear(128, 10)
+
+    def _make_equal_layers(self, in_channel, out_channel, embedding_channel):
+        layers = []
+        for d in range(3):
+            layers += [ME.MinkowskiConvolution(in_channel, out_channel, kernel_size=3, dimension=self.D)]
+            layers += [ME.MinkowskiInstanceNorm(out_channel)]
+            layers += [ME.MinkowskiReLU(inplace=True)]
+            layers += [ME.MinkowskiAvgPooling(kernel_size=2, stride=2, dimension=self.D)]
+            in_channel = 128
+        if not self.full_minkowski:
+            layers += [ME.MinkowskiConvolution(out_channel * 2, 1, kernel_size=1, dimension=self.D)]
+        return nn.Sequential(*layers)
+
+    def forward(self, x: TensorField):
+        out = x.sparse()
+        out = self.features(out)
+        if not self.full_minkowski:
+            min_coord, _ = out.C.min(0, keepdim=True)
+            min_coord = min_coord[:, 1:].cpu()
+            out = out.dense(shape=self.dense_shape, min_coordinate=min_coord)[0]   # AttributeError, as in the reference (:18,76)
+            out = out.view(out.shape[0], -1)
+            out = self.classifier(out)
+        if self.full_minkowski:
+            out = self.global_avg_pool(out)
+            out = self.classifier(out).F   # 16 channels into Linear(128, 10): shape error, as in the reference (:21,82)
+        return out
+
+
+class MEConvImage(_UnusedVariant):
+    """models/MEConv.py:86-164."""
+
+    def __init__(self, in_channel, out_channel, embedding_channel=1024, dimension=3, full_minkowski=False):
+        super().__init__(dimension)
+        self.full_minkowski = full_minkowski
+        self.features = self._make_equal_layers(in_channel, out_channel, embedding_channel)
+        self.weight_initialization()
+        if not full_minkowski:
+            self.classifier = nn.Linear(100352, 10)
+        if full_minkowski:
+            self.global_avg_pool = ME.MinkowskiGlobalAvgPooling()
+            self.classifier = ME.MinkowskiLinear(128, 10)
+
+    def _make_equal_layers(self, in_channel, out_channel, embedding_channel):
+        layers = []
+        for d in range(3):
+            layers += [ME.MinkowskiConvolution(in_channel, 128, kernel_size=3, dimension=self.D)]
+            layers += [ME.MinkowskiInstanceNorm(128)]
+            layers += [ME.MinkowskiReLU(inplace=True)]
+            layers += [ME.MinkowskiAvgPooling(kernel_size=2, stride=2, dimension=self.D)]
+            in_channel = 128
+        if not self.full_minkowski:
+            layers += [ME.MinkowskiConvolution(in_channel, 128, kernel_size=1, dimension=self.D)]
+        return nn.Sequential(*layers)
+
+    def forward(self, x: TensorField):
+        out = x.sparse()
+        B = out.coordinate_manager.B
+        out = self.features(out)
+        if not self.full_minkowski:
+            dense_shape = torch.Size([B, 1, 1, 28, 28])   # one channel asked of a 128-channel tensor, as in the reference (:152)
+            min_coord, _ = out.C.min(0, keepdim=True)
+            min_coord = min_coord[:, 1:].cpu()
+            out = out.dense(shape=dense_shape, min_coordinate=min_coord)[0]
+            out = out.view(-1, 100352)
+            out = self.classifier(out)
+        if self.full_minkowski:
+            out = self.global_avg_pool(out)
+            out = self.classifier(out).F
+        return out
 
 
 class MEPytorch(ME.MinkowskiNetwork):

@@ -180,6 +180,67 @@ class MaxPoolFn(Function):
         return g_x, None, None, None, None
 
 
+# ----------------------------------------------------------------------------------------------- the reference's unused variants (f4)
+def sparse_conv_any(X, W, nbr, ld, M_out):
+    """MinkowskiConvolution for the channel counts and kernel sizes that only the reference's UNUSED models name (models/MEConv.py:
+    25-39,102-130: 1 -> 128, 128 -> 64 -> 32 -> 16, 1x1 convolutions): Y[o] = sum_k X[nbr[k][o]] @ W[k] as gathers + library GEMMs on the
+    device.  The hand-written kernels (SparseConvFn) take Cin in {3, 128} -> 128 at kernel size 3, the shapes MEConvExp uses."""
+    K, Cin, Cout = W.shape
+    if K == 1:   # kernel_size = 1: every voxel is its own only neighbour
+        return X[:M_out] @ W[0]
+    if K == 27 and Cout == 128 and Cin in (3, 128):
+        return SparseConvFn.apply(X, W, nbr, ld, M_out)
+    Y = torch.zeros((M_out, Cout), dtype=X.dtype, device=X.device)
+    for k in range(K):
+        nb = nbr[k, :M_out].long()
+        o = torch.nonzero(nb >= 0).reshape(-1)
+        if o.numel():
+            Y = Y.index_add(0, o, X.index_select(0, nb[o]) @ W[k])
+    return Y
+
+
+class AvgPoolFn(Function):
+    """ME.MinkowskiAvgPooling(kernel_size=2, stride=2) (models/MEConv.py:28,35,105,112,126): channel-wise mean over the existing
+    children of every output voxel.  First-order backward only, like MinkowskiEngine's native pooling function."""
+
+    @staticmethod
+    def forward(ctx, X, kids, ld, parent, M_out):
+        x = _c(X)
+        C = x.shape[1]
+        out = torch.empty((M_out, C), dtype=_F32, device=x.device)
+        cnt = torch.empty((max(M_out, 1),), dtype=torch.int32, device=x.device)
+        L.call("dd3d_avg_pool_fwd", L.ptr(x), x.shape[0], C, L.ptr(kids), ld, kids.shape[0], M_out, None, L.ptr(out), L.ptr(cnt), L.stream())
+        ctx.saved = (cnt, parent, x.shape[0], M_out, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        cnt, parent, M_in, M_out, C = ctx.saved
+        dX = torch.zeros((M_in, C), dtype=_F32, device=g.device)
+        L.call("dd3d_avg_pool_bwd", L.ptr(_c(g)), L.ptr(cnt), L.ptr(parent), M_in, M_out, C, L.ptr(dX), L.stream())
+        return dX, None, None, None, None
+
+
+class GlobalAvgPoolFn(Function):
+    """ME.MinkowskiGlobalAvgPooling (models/MEConv.py:20,97): one row per cloud, the mean of the cloud's voxel features."""
+
+    @staticmethod
+    def forward(ctx, X, seg_off, B):
+        x = _c(X)
+        M, C = x.shape
+        out = torch.empty((B, C), dtype=_F32, device=x.device)
+        L.call("dd3d_global_avg_pool_fwd", L.ptr(x), M, L.ptr(seg_off), B, C, L.ptr(out), L.stream())
+        ctx.saved = (seg_off, B, M, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        seg_off, B, M, C = ctx.saved
+        dX = torch.zeros((M, C), dtype=_F32, device=g.device)
+        L.call("dd3d_global_avg_pool_bwd", L.ptr(_c(g)), M, L.ptr(seg_off), B, C, L.ptr(dX), L.stream())
+        return dX, None, None
+
+
 # ----------------------------------------------------------------------------------------------- fused norm + affine + ReLU + pool
 class _NormActPoolBwdFn(Function):
     """(g_pool, Y, w, b) -> (dY, dw, db).  Its own backward implements the only second-order term of the block:

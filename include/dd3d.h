@@ -206,6 +206,18 @@ int dd3d_affine_relu_pool_fwd(const float* xhat, const float* w, const float* b,
 int dd3d_inorm_arp_fwd(const float* Y, const int32_t* seg_off, int B, int C, float* xhat, float* inv_std, const float* w, const float* b,
                        const int32_t* kids, int64_t ld, int Kp, const int32_t* seg_out, float* pooled, int32_t* arg, void* stream);
 
+/* MinkowskiAvgPooling(kernel_size=2, stride=2) of the reference's unused model variants (models/MEConv.py:28,35,105,112,126):
+ * out[v][C] = mean of the existing children of v (kids[Kp<=8][ld], -1 = none; the divisor is the number of children that exist),
+ * cnt[v] = that number (kept for the backward).  C % 4 == 0.  M_out may be a bound when m_dev (device int) is given.
+ * Backward: every input row has exactly one parent, dX[i] = g[parent[i]] / cnt[parent[i]]. */
+int dd3d_avg_pool_fwd(const float* X, int64_t M_in, int C, const int32_t* kids, int64_t ld, int Kp, int64_t M_out, const int32_t* m_dev, float* out,
+                      int32_t* cnt, void* stream);
+int dd3d_avg_pool_bwd(const float* g, const int32_t* cnt, const int32_t* parent, int64_t M_in, int64_t M_out, int C, float* dX, void* stream);
+/* MinkowskiGlobalAvgPooling (models/MEConv.py:20,97): out[b][C] = mean over the rows [seg_off[b], seg_off[b+1]) of cloud b (zeros for an
+ * empty cloud); backward dX[i] = g[b] / rows(b). */
+int dd3d_global_avg_pool_fwd(const float* X, int64_t M, const int32_t* seg_off, int B, int C, float* out, void* stream);
+int dd3d_global_avg_pool_bwd(const float* g, int64_t M, const int32_t* seg_off, int B, int C, float* dX, void* stream);
+
 /* backward of the same three ops for every input row; gw_w/gw_b[G,C] are the per-group affine gradients (nullable pair);
  * ga_out (nullable) keeps the ReLU-masked pooled gradient; ga_prev + gw_extra[G,C] (nullable pair) add ga_prev*gw_extra[group]. */
 int64_t dd3d_arp_bwd_ws_bytes(int64_t M_in, int G);

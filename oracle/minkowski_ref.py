@@ -379,13 +379,18 @@ class MinkowskiConvolution(nn.Module):
         self.kernel_size = kernel_size
         self.kernel_volume = kernel_size ** 3
         self.in_channels, self.out_channels = in_channels, out_channels
-        self.kernel = nn.Parameter(torch.empty(self.kernel_volume, in_channels, out_channels))
+        # kernel volume 1 (kernel_size=1, only in the reference's unused models): a 2-D [Cin, Cout] parameter, as in MinkowskiEngine
+        self.kernel = nn.Parameter(torch.empty(in_channels, out_channels) if self.kernel_volume == 1
+                                   else torch.empty(self.kernel_volume, in_channels, out_channels))
         stdv = 1.0 / math.sqrt(in_channels * self.kernel_volume)
         with torch.no_grad():
             self.kernel.uniform_(-stdv, stdv)
 
     def forward(self, x: SparseTensor):
         ts = x.tensor_stride
+        if self.kernel_volume == 1:
+            nbr = torch.arange(x.F.shape[0], dtype=torch.int64)[None]
+            return SparseTensor(SparseConvFn.apply(x.F, self.kernel[None], nbr), x.C, ts, x.coordinate_manager)
         nbr = x.coordinate_manager.get_kernel_map(ts, ts, self.kernel_size)
         Y = SparseConvFn.apply(x.F, self.kernel, nbr)
         return SparseTensor(Y, x.C, ts, x.coordinate_manager)
@@ -443,6 +448,88 @@ class MinkowskiMaxPooling(nn.Module):
         return "MinkowskiMaxPooling(kernel_size=[2, 2, 2], stride=[2, 2, 2], dilation=[1, 1, 1])"
 
 
+class AvgPoolFn(Function):
+    """MinkowskiLocalPoolingFunction, AVERAGE mode: mean over the children that exist (the divisor is the number of inputs mapped to
+    the output).  kids[Kp, M_out] = child rows or -1.  Opaque (first-order) backward like the other native functions.
+    Parity unpinned: MinkowskiEngine is absent; only the reference's UNUSED models name this layer (models/MEConv.py:28,35,105,112,126)."""
+
+    @staticmethod
+    def forward(ctx, X, kids):
+        Kp, Mo = kids.shape
+        s = torch.zeros((Mo, X.shape[1]), dtype=X.dtype)
+        n = torch.zeros((Mo, 1), dtype=X.dtype)
+        for k in range(Kp):
+            have = (kids[k] >= 0)[:, None]
+            s = s + torch.where(have, X[kids[k].clamp(min=0)], torch.zeros_like(s))
+            n = n + have.to(X.dtype)
+        ctx.save_for_backward(kids, n)
+        ctx.Mi = X.shape[0]
+        return s / n.clamp(min=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        kids, n = ctx.saved_tensors
+        with torch.no_grad():
+            dX = torch.zeros(ctx.Mi, g.shape[1], dtype=g.dtype)
+            gn = g / n.clamp(min=1)
+            for k in range(kids.shape[0]):
+                o = torch.nonzero(kids[k] >= 0).reshape(-1)
+                dX.index_add_(0, kids[k][o], gn[o])
+        return dX, None
+
+
+class GlobalAvgPoolFn(Function):
+    """MinkowskiGlobalPoolingFunction, AVERAGE mode: one row per batch index, the mean of its voxels' features (opaque backward)."""
+
+    @staticmethod
+    def forward(ctx, X, bidx, B):
+        cnt = torch.bincount(bidx, minlength=B).to(X.dtype).clamp_(min=1)[:, None]
+        ctx.save_for_backward(bidx, cnt)
+        return _seg_sum(X, bidx, B) / cnt
+
+    @staticmethod
+    def backward(ctx, g):
+        bidx, cnt = ctx.saved_tensors
+        with torch.no_grad():
+            dX = (g / cnt)[bidx]
+        return dX, None, None
+
+
+class MinkowskiAvgPooling(nn.Module):
+    def __init__(self, kernel_size, stride=1, dilation=1, dimension=None):
+        super().__init__()
+        assert kernel_size == 2 and stride == 2 and dilation == 1 and dimension == 3
+        self.kernel_size, self.stride = kernel_size, stride
+
+    def forward(self, x: SparseTensor):
+        ts = x.tensor_stride
+        cm = x.coordinate_manager
+        Cout = cm.get_stride_map(ts, ts * self.stride)
+        kids = cm.get_kernel_map(ts, ts * self.stride, self.kernel_size)
+        return SparseTensor(AvgPoolFn.apply(x.F, kids), Cout, ts * self.stride, cm)
+
+
+class _Pooled:
+    def __init__(self, F):
+        self.F = F
+
+
+class MinkowskiGlobalAvgPooling(nn.Module):
+    def forward(self, x: SparseTensor):
+        b = x.C[:, 0].to(torch.int64)
+        B = int(b.max().item()) + 1 if b.numel() else 0
+        return _Pooled(GlobalAvgPoolFn.apply(x.F, b, B))
+
+
+class MinkowskiLinear(nn.Module):
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.linear = nn.Linear(in_features, out_features, bias=bias)
+
+    def forward(self, x):
+        return _Pooled(self.linear(x.F))
+
+
 def _unavailable(name):
     class _U(nn.Module):
         def __init__(self, *a, **k):
@@ -451,9 +538,6 @@ def _unavailable(name):
     return _U
 
 
-MinkowskiAvgPooling = _unavailable("MinkowskiAvgPooling")
-MinkowskiGlobalAvgPooling = _unavailable("MinkowskiGlobalAvgPooling")
-MinkowskiLinear = _unavailable("MinkowskiLinear")
 MinkowskiBatchNorm = _unavailable("MinkowskiBatchNorm")
 
 
@@ -480,7 +564,7 @@ def sparse_collate(coords: Sequence[torch.Tensor], feats: Sequence[torch.Tensor]
 
 def kaiming_normal_(tensor, a=0, mode="fan_in", nonlinearity="leaky_relu"):
     """ME.utils.kaiming_normal_ for a [K, in, out] kernel (models/MEConv.py:237-238)."""
-    K, cin, cout = tensor.shape
+    K, cin, cout = tensor.shape if tensor.dim() == 3 else (1, *tensor.shape)
     fan = cin * K if mode == "fan_in" else cout * K
     gain = nn.init.calculate_gain(nonlinearity, a)
     std = gain / math.sqrt(fan)

@@ -14,6 +14,7 @@ Fixtures (data only; inputs are regenerated from tests/detgen.py seeds by the te
   g3_mepytorch.npz    reference MEPytorch: one matching step (2 classes x 4 real, ipc 2)
   g4_meconvexp.npz    reference MEConvExp topology over the ME restatement: one matching step, modmse + ours
   g5_ctor.npz         constructor parameter names / shapes / order
+  g7_unused_models.npz  the unused MEConv / MEConvImage: names / shapes; one forward + backward of MEConvImage(full_minkowski=True)
   g6_eval.npz         evaluation block: reference models/MNIST.py ConvNet (names, shapes, seeded forward) and
                       mnist_distill.py populate_img / augment / epoch on seeded inputs (open3d, torchinfo, torchvision.utils are
                       name-only stand-ins: none of them is reached by these functions)
@@ -244,6 +245,36 @@ def g6(settings):
     np.savez_compressed(os.path.join(HERE, "g6_eval.npz"), **out)
 
 
+def g7(settings, Mnist2D, MEConv):
+    """The reference's UNUSED models (models/MEConv.py:10-164) over the ME restatement: constructor names / shapes of MEConv and
+    MEConvImage in both modes, and one forward + backward of the only configuration that runs, MEConvImage(full_minkowski=True)."""
+    out = {}
+    for name, cls in (("MEConv", MEConv.MEConv), ("MEConvImage", MEConv.MEConvImage)):
+        for full in (False, True):
+            net = cls(in_channel=3, out_channel=10, full_minkowski=full)
+            tag = f"{name}.{'full' if full else 'dense'}"
+            out[tag + ".names"] = np.array([n for n, _ in net.named_parameters()])
+            out[tag + ".shapes"] = np.array([str(tuple(p.shape)) for p in net.parameters()])
+            out[tag + ".sd_keys"] = np.array(list(net.state_dict().keys()))
+    torch.manual_seed(0)
+    net = MEConv.MEConvImage(in_channel=3, out_channel=10, full_minkowski=True)
+    out["MEConvImage.kernel_std"] = np.array([net.features[i].kernel.std().item() for i in (0, 4, 8)])
+    net.load_state_dict(det_state_dict(net, "net.MEConvImage"))
+    net.train()
+    imgs = torch.cat([stroke_digits(3, seed=300 + c) for c in range(2)])
+    labels = torch.tensor([0, 0, 0, 1, 1, 1])
+    for batch in Mnist2D.get_mnist_dataloader(Mnist2D.Mnist2Dreal(imgs, labels, False), imgs.shape[0]):
+        tf = MEConv.create_input_batch(batch, True, device="cpu", quantization_size=1)
+        logits = net(tf)
+        loss = torch.nn.CrossEntropyLoss()(logits, batch["labels"])
+    grads = torch.autograd.grad(loss, list(net.parameters()))
+    out["fwd.logits"] = logits.detach().numpy()
+    out["fwd.loss"] = np.array(loss.item())
+    out["fwd.grad_norm"] = np.array([g.double().norm().item() for g in grads])
+    out["fwd.grad_kernel0"] = grads[0].detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "g7_unused_models.npz"), **out)
+
+
 def main():
     settings = install_stubs()
     sys.path.insert(0, REF)
@@ -251,12 +282,17 @@ def main():
     from models import MEConv
     from utils import Mnist2D
 
+    if "--only-g7" in sys.argv:
+        g7(settings, Mnist2D, MEConv)
+        print("g7 written to", HERE)
+        return
     g1(settings, dl)
     g2(settings, Mnist2D, MEConv)
     run_model_fixture(settings, Mnist2D, MEConv, dl, MEConv.MEPytorch, True, "g3_mepytorch.npz", ["modmse", "ours"])
     run_model_fixture(settings, Mnist2D, MEConv, dl, MEConv.MEConvExp, False, "g4_meconvexp.npz", ["modmse", "ours"])
     g5(MEConv)
     g6(settings)
+    g7(settings, Mnist2D, MEConv)
     print("golden fixtures written to", HERE)
 
 
