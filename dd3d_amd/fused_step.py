@@ -548,6 +548,12 @@ class FusedDistiller:
         self._graph = self._static = None
         self._graph_stamp, self._needs_eager, self._last_loss = None, False, None
         self._scope = "graph%x" % id(self)
+        if self.use_graph:
+            # An earlier distiller that was dropped (captured graphs, side-stream tensors, workspace scope: it sits in reference cycles)
+            # is collected HERE, with nothing of this one enqueued yet, not wherever the cyclic collector happens to run -- e.g. inside
+            # this distiller's first multi-stream step.  torch.cuda.graph() does the same before every capture.
+            import gc
+            gc.collect()
 
     def _param_stamp(self):
         """(address, version) of every network parameter: what the captured graph and its cached weight layouts were built from."""

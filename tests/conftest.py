@@ -20,3 +20,18 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _quiescent_teardown():
+    """GPU tests leave distillers behind (captured HIP graphs, side-stream tensors, workspace scopes) that sit in reference cycles.
+    Collect them HERE, with the device idle, instead of wherever the cyclic collector happens to run -- e.g. inside the next test's
+    first multi-stream step (a full-suite run once aborted in a collection pass at exactly such a point, without any GPU fault
+    reported)."""
+    yield
+    import torch
+    if torch.cuda.is_available():
+        import gc
+        torch.cuda.synchronize()
+        gc.collect()
+        torch.cuda.synchronize()
