@@ -548,12 +548,6 @@ class FusedDistiller:
         self._graph = self._static = None
         self._graph_stamp, self._needs_eager, self._last_loss = None, False, None
         self._scope = "graph%x" % id(self)
-        if self.use_graph:
-            # An earlier distiller that was dropped (captured graphs, side-stream tensors, workspace scope: it sits in reference cycles)
-            # is collected HERE, with nothing of this one enqueued yet, not wherever the cyclic collector happens to run -- e.g. inside
-            # this distiller's first multi-stream step.  torch.cuda.graph() does the same before every capture.
-            import gc
-            gc.collect()
 
     def _param_stamp(self):
         """(address, version) of every network parameter: what the captured graph and its cached weight layouts were built from."""
@@ -974,7 +968,14 @@ class FusedDistiller:
                 self.invalidate()   # a weight changed (load_state_dict, optimizer step): the captured graph reads stale cached layouts
             parity = self.steps_done % 2 if self.defer else 0
             if force_eager or self.steps_done == 0 or self._needs_eager:
-                # the first step runs eagerly: it sizes the workspaces and builds the cached weight layouts the graph will reuse
+                # the first step runs eagerly: it sizes the workspaces and builds the cached weight layouts the graph will reuse.
+                # An earlier distiller that was dropped (captured graphs, side-stream tensors, workspace scope: it sits in reference
+                # cycles) is collected HERE, before anything is enqueued, not wherever the cyclic collector happens to run inside the
+                # multi-stream step (a full-suite run aborted once in such a collection pass); torch.cuda.graph() does the same
+                # before every capture.
+                if self.steps_done == 0:
+                    import gc
+                    gc.collect()
                 loss = self._static_body(parity)
                 self._needs_eager = False
             else:
