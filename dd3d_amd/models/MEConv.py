@@ -72,83 +72,71 @@ class MEConvExp(ME.MinkowskiNetwork):
         return ops.sparse_linear(f, self.classifier.weight, self.classifier.bias, dp)
 
 
+def _avg_block(cin, cout, D):
+    """conv k3 -> instance norm -> ReLU -> average pooling k2 s2: the repeating unit of both unused stacks."""
+    return [ME.MinkowskiConvolution(cin, cout, kernel_size=3, dimension=D), ME.MinkowskiInstanceNorm(cout), ME.MinkowskiReLU(inplace=True),
+            ME.MinkowskiAvgPooling(kernel_size=2, stride=2, dimension=D)]
+
+
 class _UnusedVariant(ME.MinkowskiNetwork):
-    """Shared body of the reference's two UNUSED models (models/MEConv.py:10-164; nothing in mnist_distill.py builds them): layer
-    stacks with MinkowskiAvgPooling, and either a dense Linear head or, with ``full_minkowski=True``, MinkowskiGlobalAvgPooling +
-    MinkowskiLinear(128, 10).  Constructors, module trees, parameter names and initialisation follow the reference line by line --
-    including what does not work there: ``MEConv`` never defines ``dense_shape`` (its dense head raises AttributeError, :76) and its
-    full-Minkowski head feeds 16 channels into Linear(128, 10) (:21,81-82); ``MEConvImage``'s dense head asks ``dense()`` for one
-    channel of a 128-channel tensor (:152-156).  The one configuration that runs in the reference, MEConvImage(full_minkowski=True),
-    runs here on the HIP kernels (convolutions, instance norm, average pooling, global average pooling)."""
+    """Shared body of the reference's two UNUSED models (models/MEConv.py:10-164; nothing in mnist_distill.py builds them): stacks of
+    the block above, closed by a 1x1 convolution and a dense Linear head or, with ``full_minkowski=True``, by
+    MinkowskiGlobalAvgPooling + MinkowskiLinear(128, 10).  Constructors, module trees, parameter names and initialisation are the
+    reference's -- including what does not work there: ``MEConv`` never defines ``dense_shape`` (its dense head raises
+    AttributeError, :76) and its full-Minkowski head feeds 16 channels into Linear(128, 10) (:21,81-82); ``MEConvImage``'s dense head
+    asks ``dense()`` for one channel of a 128-channel tensor (:152-156).  The one configuration that runs in the reference,
+    MEConvImage(full_minkowski=True), runs here on the HIP kernels (convolutions, instance norm, average pooling, global average
+    pooling).  The two layer builders are tables of (in, out) widths; both classes carry both builders, as in the reference."""
+
+    def _stack(self, widths, tail):
+        layers = [m for cin, cout in widths for m in _avg_block(cin, cout, self.D)]
+        if not self.full_minkowski:   # the dense heads sit behind a closing kernel-size-1 convolution
+            layers.append(ME.MinkowskiConvolution(tail[0], tail[1], kernel_size=1, dimension=self.D))
+        return nn.Sequential(*layers)
 
     def _make_layers(self, in_channel, out_channel, embedding_channel):
-        layers = []
-        layers += [ME.MinkowskiConvolution(in_channel, 128, kernel_size=3, dimension=self.D)]
-        layers += [ME.MinkowskiInstanceNorm(128)]
-        layers += [ME.MinkowskiReLU(inplace=True)]
-        layers += [ME.MinkowskiAvgPooling(kernel_size=2, stride=2, dimension=self.D)]
-        in_channel = 128
-        out_channel = 64
-        for d in range(3):
-            layers += [ME.MinkowskiConvolution(in_channel, out_channel, kernel_size=3, dimension=self.D)]
-            layers += [ME.MinkowskiInstanceNorm(out_channel)]
-            layers += [ME.MinkowskiReLU(inplace=True)]
-            layers += [ME.MinkowskiAvgPooling(kernel_size=2, stride=2, dimension=self.D)]
-            in_channel //= 2
-            out_channel //= 2
-        if not self.full_minkowski:
-            layers += [ME.MinkowskiConvolution(out_channel * 2, 1, kernel_size=1, dimension=self.D)]
-        return nn.Sequential(*layers)
+        # (:22-41, :99-118) 128 channels, then three halvings; the arguments beyond the first do not reach the widths
+        return self._stack([(in_channel, 128), (128, 64), (64, 32), (32, 16)], (16, 1))
 
     def weight_initialization(self):
         for m in self.modules():
-            if isinstance(m, ME.MinkowskiLinear):
-                ME.kaiming_normal_(m.kernel, mode="fan_out", nonlinearity="relu")   # (as in the reference: MinkowskiLinear has no .kernel)
-            if isinstance(m, ME.MinkowskiConvolution):
+            if isinstance(m, (ME.MinkowskiLinear, ME.MinkowskiConvolution)):   # (a MinkowskiLinear has no .kernel: it would raise, as in the reference)
                 ME.kaiming_normal_(m.kernel, mode="fan_out", nonlinearity="relu")
-            if isinstance(m, ME.MinkowskiBatchNorm):
+            elif isinstance(m, ME.MinkowskiBatchNorm):
                 nn.init.constant_(m.bn.weight, 1)
                 nn.init.constant_(m.bn.bias, 0)
 
+    def _heads(self, full_minkowski, dense_in):
+        if full_minkowski:
+            self.global_avg_pool = ME.MinkowskiGlobalAvgPooling()
+            self.classifier = ME.MinkowskiLinear(128, 10)
+        else:
+            self.classifier = nn.Linear(dense_in, 10)
+
+    def _pooled_head(self, out):
+        return self.classifier(self.global_avg_pool(out)).F
+
 
 class MEConv(_UnusedVariant):
-    """models/MEConv.py:10-84."""
+    """models/MEConv.py:10-84 (no weight_initialization in its constructor; one input channel whatever ``in_channel`` says, :15)."""
 
     def __init__(self, in_channel, out_channel, embedding_channel=1024, dimension=3, full_minkowski=False):
         super().__init__(dimension)
         self.full_minkowski = full_minkowski
         self.features = self._make_layers(1, out_channel, embedding_channel)
-        if not full_minkowski:
-            self.classifier = nn.Linear(4500, 10)
-        if full_minkowski:
-            self.global_avg_pool = ME.MinkowskiGlobalAvgPooling()
-            self.classifier = ME.MinkowskiLinear(128, 10)
+        self._heads(full_minkowski, 4500)
 
     def _make_equal_layers(self, in_channel, out_channel, embedding_channel):
-        layers = []
-        for d in range(3):
-            layers += [ME.MinkowskiConvolution(in_channel, out_channel, kernel_size=3, dimension=self.D)]
-            layers += [ME.MinkowskiInstanceNorm(out_channel)]
-            layers += [ME.MinkowskiReLU(inplace=True)]
-            layers += [ME.MinkowskiAvgPooling(kernel_size=2, stride=2, dimension=self.D)]
-            in_channel = 128
-        if not self.full_minkowski:
-            layers += [ME.MinkowskiConvolution(out_channel * 2, 1, kernel_size=1, dimension=self.D)]
-        return nn.Sequential(*layers)
+        # (:43-54) three blocks of ``out_channel`` channels, closed by 2 * out_channel -> 1
+        return self._stack([(in_channel, out_channel), (128, out_channel), (128, out_channel)], (out_channel * 2, 1))
 
     def forward(self, x: TensorField):
-        out = x.sparse()
-        out = self.features(out)
-        if not self.full_minkowski:
-            min_coord, _ = out.C.min(0, keepdim=True)
-            min_coord = min_coord[:, 1:].cpu()
-            out = out.dense(shape=self.dense_shape, min_coordinate=min_coord)[0]   # AttributeError, as in the reference (:18,76)
-            out = out.view(out.shape[0], -1)
-            out = self.classifier(out)
+        out = self.features(x.sparse())
         if self.full_minkowski:
-            out = self.global_avg_pool(out)
-            out = self.classifier(out).F   # 16 channels into Linear(128, 10): shape error, as in the reference (:21,82)
-        return out
+            return self._pooled_head(out)   # 16 channels into Linear(128, 10): shape error, as in the reference (:21,82)
+        min_coord = out.C.min(0, keepdim=True)[0][:, 1:].cpu()
+        dense = out.dense(shape=self.dense_shape, min_coordinate=min_coord)[0]   # AttributeError, as in the reference (:18,76)
+        return self.classifier(dense.view(dense.shape[0], -1))
 
 
 class MEConvImage(_UnusedVariant):
@@ -158,40 +146,23 @@ class MEConvImage(_UnusedVariant):
         super().__init__(dimension)
         self.full_minkowski = full_minkowski
         self.features = self._make_equal_layers(in_channel, out_channel, embedding_channel)
-        self.weight_initialization()
-        if not full_minkowski:
-            self.classifier = nn.Linear(100352, 10)
-        if full_minkowski:
-            self.global_avg_pool = ME.MinkowskiGlobalAvgPooling()
-            self.classifier = ME.MinkowskiLinear(128, 10)
+        self.weight_initialization()   # before the head exists (:92): the convolutions only
+        self._heads(full_minkowski, 100352)
 
     def _make_equal_layers(self, in_channel, out_channel, embedding_channel):
-        layers = []
-        for d in range(3):
-            layers += [ME.MinkowskiConvolution(in_channel, 128, kernel_size=3, dimension=self.D)]
-            layers += [ME.MinkowskiInstanceNorm(128)]
-            layers += [ME.MinkowskiReLU(inplace=True)]
-            layers += [ME.MinkowskiAvgPooling(kernel_size=2, stride=2, dimension=self.D)]
-            in_channel = 128
-        if not self.full_minkowski:
-            layers += [ME.MinkowskiConvolution(in_channel, 128, kernel_size=1, dimension=self.D)]
-        return nn.Sequential(*layers)
+        # (:120-132) three blocks of 128 channels, closed by 128 -> 128
+        return self._stack([(in_channel, 128), (128, 128), (128, 128)], (128, 128))
 
     def forward(self, x: TensorField):
         out = x.sparse()
         B = out.coordinate_manager.B
         out = self.features(out)
-        if not self.full_minkowski:
-            dense_shape = torch.Size([B, 1, 1, 28, 28])   # one channel asked of a 128-channel tensor, as in the reference (:152)
-            min_coord, _ = out.C.min(0, keepdim=True)
-            min_coord = min_coord[:, 1:].cpu()
-            out = out.dense(shape=dense_shape, min_coordinate=min_coord)[0]
-            out = out.view(-1, 100352)
-            out = self.classifier(out)
         if self.full_minkowski:
-            out = self.global_avg_pool(out)
-            out = self.classifier(out).F
-        return out
+            return self._pooled_head(out)
+        min_coord = out.C.min(0, keepdim=True)[0][:, 1:].cpu()
+        # one channel asked of a 128-channel tensor, as in the reference (:152-156)
+        dense = out.dense(shape=torch.Size([B, 1, 1, 28, 28]), min_coordinate=min_coord)[0]
+        return self.classifier(dense.view(-1, 100352))
 
 
 class MEPytorch(ME.MinkowskiNetwork):
