@@ -61,6 +61,19 @@ def conv_kernel_gradient(X, Cin, dY, nbr, ld, M, gro, G, dev, seg=None, B=0, err
 _COUNTERS = {}
 
 
+def _cw_site_major():
+    """Layout of the per-class classifier-weight gradients inside the step: [G, J, S, 128] (sites outside the channels; default) or the
+    parameter's own [G, J, 128, S] (DD3D_CW_LAYOUT=cs).  With the channels innermost ``k_sl_bwd_w`` writes whole 512-byte rows instead of
+    4-byte elements S floats apart (cfg4: 562 MB of gradients, 18 ms -> see DESIGN.md), and the second-order pass reads the loss
+    gradient through the same strides without a layout launch.  The matching loss only needs the J rows to be contiguous, which both are."""
+    return os.environ.get("DD3D_CW_LAYOUT", "sc") != "cs"
+
+
+def _cw_strides(J, C, S):
+    """(group, output, channel, site) strides of that layout, in floats."""
+    return (ctypes.c_int64 * 4)(J * C * S, C * S, 1, C) if _cw_site_major() else (ctypes.c_int64 * 4)(J * C * S, C * S, S, 1)
+
+
 def _group_counters(dev, G):
     """G zero ints for the kernels that elect a group's last workgroup (they leave the counters at zero): one buffer per device, zeroed once."""
     buf = _COUNTERS.get(dev)
@@ -224,7 +237,7 @@ class _Pass:
                 if self.dl_scale is not None:   # (the bias gradient of the SCALED logit gradients)
                     L.call("dd3d_group_sum_rows", L.ptr(dl), L.ptr(group_cloud_off), G, J, L.ptr(g_cb), L.stream())
                 g_cw = _empty((G, J, 128 * S), dev)
-                pst = (ctypes.c_int64 * 4)(J * 128 * S, 128 * S, S, 1)
+                pst = _cw_strides(J, 128, S)
                 L.call("dd3d_sparse_linear_bwd_w", L.ptr(dl), L.ptr(P1), L.ptr(dp.vox_at), S, B, L.ptr(group_cloud_off), G, 128, J, L.ptr(g_cw), pst,
                        g_cw.numel(), L.stream())
                 self.ev_cls = torch.cuda.Event()
@@ -318,16 +331,19 @@ class _Pass:
         # rows of the synthetic clouds at strides 1 / 2 (device-side counts; their bound is the number of synthetic points)
         m1s, m2s = seg1[Bs:].data_ptr(), seg2[Bs:].data_ptr()
         sst = _site_strides(J, 128, S)
-        Gsm = _empty((Gs, S, J, 128), dev)
-        L.call("dd3d_classifier_layout", L.ptr(G_cw), Gs, J, 128, S, 0, L.ptr(Gsm), st)
+        if _cw_site_major():   # the loss gradient already has the channels innermost: read through its strides, no layout launch
+            Gsm, gst = G_cw, _cw_strides(J, 128, S)
+        else:
+            Gsm, gst = _empty((Gs, S, J, 128), dev), sst
+            L.call("dd3d_classifier_layout", L.ptr(G_cw), Gs, J, 128, S, 0, L.ptr(Gsm), st)
         # u = dL/d(dlogits): through gw[W] = dlogits^T dense and gw[b] = sum dlogits (the latter is added inside softmax_ce_bwd2)
         u = _empty((Bs, J), dev)
-        sl_fwd_call(self.P1, dp, self.cloud_group, Gsm, sst, J, None, u, Bs, Ns)
+        sl_fwd_call(self.P1, dp, self.cloud_group, Gsm, gst, J, None, u, Bs, Ns)
         dz = _empty((Bs, J), dev)
         L.call("dd3d_softmax_ce_bwd2", L.ptr(self.prob), L.ptr(u), L.ptr(G_cb), L.ptr(self.gco), Gs, J, per, L.ptr(dz), st)
         # H = dL/dP1: through dense in gw[W] (weights G_cw, coefficients dlogits) and through the logits (weights W, coefficients dz)
         H = _empty((Ns, 128), dev)
-        sl_bwd_x_call(self.dl, dp, self.cloud_group, Gsm, sst, J, 0, H, Bs, Ns)
+        sl_bwd_x_call(self.dl, dp, self.cloud_group, Gsm, gst, J, 0, H, Bs, Ns)
         sl_bwd_x_call(dz, dp, None, self.Wsm, sst, J, 1, H, Bs, Ns)
         hY1, _, _ = self._arp_inorm_bwd(H, self.arg1, cm.parent(4), self.xh1, self.is1, w5, b5, seg2, Ns, Bs, Gs, None, 0, False, self.ga1, G_w5)
         hP0 = _empty((Ns, 128), dev)
@@ -406,17 +422,21 @@ class _GradList(list):
     def __init__(self, tensors, full, compact, C=128):
         super().__init__(tensors)
         self._full, self._compact, self._C, self._same = tuple(full), tuple(compact), C, tuple(full) == tuple(compact)
+        self._site_major = _cw_site_major()   # the step holds the entry as [G, J, S, C] (see _cw_site_major)
 
     def compact(self, i):
         return list.__getitem__(self, i)
 
     def __getitem__(self, i):
-        if i in (6, -2) and not self._same:
+        if i in (6, -2) and (not self._same or self._site_major):
             t = list.__getitem__(self, 6)
             G, J = t.shape[0], t.shape[1]
             S = self._full[0] * self._full[1] * self._full[2]
+            t = t.reshape(G, J, -1, self._C).permute(0, 1, 3, 2) if self._site_major else t.reshape(G, J, self._C, -1)   # -> [G, J, C, sites held]
+            if self._same:
+                return t.reshape(G, J, self._C * S)
             out = torch.zeros((G, J, self._C, S), dtype=t.dtype, device=t.device)
-            out[..., reachable_sites(self._full, self._compact).to(t.device)] = t.reshape(G, J, self._C, -1)
+            out[..., reachable_sites(self._full, self._compact).to(t.device)] = t
             return out.reshape(G, J, self._C * S)
         return list.__getitem__(self, i)
 
