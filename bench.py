@@ -145,7 +145,9 @@ def main():
                          "dd3d_conv128_ordered": lambda a: True,                        # forward (a[8] == 0) and mirrored = backward-data launch
                          "dd3d_conv_bwd_data": lambda a: a[5] == 128,
                          "dd3d_inorm_arp_fwd": lambda a: True,
-                         "dd3d_arp_inorm_bwd": lambda a: a[18] is not None})            # the first-order launches (they also reduce the affine gradients)
+                         "dd3d_inorm_arp_fwd_y": lambda a: True,                        # (the step's launch: no normalised rows in memory)
+                         "dd3d_arp_inorm_bwd": lambda a: a[18] is not None,             # the first-order launches (they also reduce the affine gradients)
+                         "dd3d_arp_inorm_bwd_y": lambda a: a[19] is not None})
     nbr_keep = []
     orig_apply_fwd = _ops.SparseConvFn.forward
 
@@ -259,15 +261,16 @@ def main():
                 f[1] += nbytes
             lv = 0
             for (n, t, a) in rec:
-                if n == "dd3d_inorm_arp_fwd":
+                if n in ("dd3d_inorm_arp_fwd", "dd3d_inorm_arp_fwd_y"):
                     mi, mo = ((M0, M1), (M1, M2))[lv % 2]
-                    add("instance norm + affine + ReLU + max-pool forward (k_inorm_arp_fwd)", t, 1024.0 * mi + 1024.0 * mo)
+                    # Y read (+ xhat written by the stored-xhat launch), pooled + arg written
+                    add("instance norm + affine + ReLU + max-pool forward (k_inorm_arp_fwd)", t, (512.0 if n.endswith("_y") else 1024.0) * mi + 1024.0 * mo)
                     lv += 1
                 elif n == "dd3d_conv_fwd" and a[2] == 3:
                     add("first-layer convolution forward (k_conv3_fwd)", t, 4.0 * (3 * M0 + 128 * M0) + 8.0 * P0 + 4 * 27 * 3 * 128)
             lv = 0
             for (n, t, a) in rec:
-                if n == "dd3d_arp_inorm_bwd":
+                if n in ("dd3d_arp_inorm_bwd", "dd3d_arp_inorm_bwd_y"):
                     mi, mo = ((M1, M2), (M0, M1))[lv % 2]
                     add("pool + ReLU + affine + instance norm backward (k_arp_inorm_bwd)", t, 1024.0 * mi + 1024.0 * mo)
                     lv += 1

@@ -68,6 +68,7 @@ _SIGS = {
     "dd3d_inorm_fwd": (I32, [P, P, I32, I32, P, P, P]),
     "dd3d_inorm_bwd": (I32, [P, P, P, P, I32, I32, P, P]),
     "dd3d_inorm_arp_fwd": (I32, [P, P, I32, I32, P, P, P, P, P, I64, I32, P, P, P, P]),
+    "dd3d_inorm_arp_fwd_y": (I32, [P, P, I32, I32, P, P, P, P, P, I64, I32, P, P, P, P]),
     "dd3d_affine_relu_pool_fwd": (I32, [P, P, P, I32, I32, P, I64, I32, I64, P, P, P, P]),
     "dd3d_avg_pool_fwd": (I32, [P, I64, I32, P, I64, I32, I64, P, P, P, P]),
     "dd3d_avg_pool_bwd": (I32, [P, P, P, I64, I64, I32, P, P]),
@@ -77,6 +78,7 @@ _SIGS = {
     "dd3d_affine_relu_pool_bwd": (I32, [P, P, P, P, P, P, I32, I32, I64, P, I32, P, P, P, P, P, P, P, I64, P]),
     "dd3d_arp_inorm_bwd_ws_bytes": (I64, [I32]),
     "dd3d_arp_inorm_bwd": (I32, [P, P, P, P, P, P, P, I32, P, I32, P, P, I32, P, P, I32, P, P, P, P, P, I64, P]),
+    "dd3d_arp_inorm_bwd_y": (I32, [P, P, P, P, P, P, P, P, I32, P, I32, P, P, I32, P, P, I32, P, P, P, P, P, I64, P]),
     "dd3d_arp_inorm_bwd_static_max_clouds": (I32, []),
     "dd3d_arp_inorm_bwd_static": (I32, [P, P, P, P, P, P, P, I32, P, I32, P, P, I32, P, P, I32, P, P, P, P, P]),
     "dd3d_scale_rows_by_group": (I32, [P, P, P, I32, I64, I32, P, P]),

@@ -199,8 +199,12 @@ __global__ __launch_bounds__(RL * 32) void k_inorm_bwd(const f32x4* __restrict__
 
 // ---- fused affine + ReLU + max-pool (k=2, s=2) ------------------------------------------------
 // one pooled row x one float4 channel lane of k_arp_fwd (shared with the fused instance-norm kernel)
+// NORM: ``xhat`` holds the norm's INPUT rows and a row is normalised as it is read, (row - mu) * is -- the same two roundings that
+// produce a stored xhat row, so both forms give the same bits
+template <bool NORM = false>
 __device__ __forceinline__ void arp_row(const f32x4* __restrict__ xhat, const int* __restrict__ kids, int64_t ld, int Kp, int64_t o, int c4, f32x4 ww,
-                                        f32x4 bb, int use_affine_relu, f32x4* __restrict__ out, int4* __restrict__ arg) {
+                                        f32x4 bb, int use_affine_relu, f32x4* __restrict__ out, int4* __restrict__ arg,
+                                        f32x4 mu = (f32x4){0.f, 0.f, 0.f, 0.f}, f32x4 is = (f32x4){1.f, 1.f, 1.f, 1.f}) {
     const float ninf = -__builtin_inff();
     f32x4 best = {ninf, ninf, ninf, ninf};
     int4 a = make_int4(-1, -1, -1, -1);
@@ -217,6 +221,7 @@ __device__ __forceinline__ void arp_row(const f32x4* __restrict__ xhat, const in
         const int i = ch[k];
         if (k >= Kp || i < 0) continue;
         f32x4 v = rows[k];
+        if (NORM) v = (v - mu) * is;
         if (use_affine_relu) {
             v = v * ww + bb;
 #pragma unroll
@@ -252,13 +257,16 @@ template <int RL, int CACHE>
 __global__ __launch_bounds__(RL * 32) void k_inorm_arp_fwd(const f32x4* __restrict__ Y, const int* __restrict__ seg_off, f32x4* __restrict__ xhat,
                                                            f32x4* __restrict__ inv_std, const f32x4* __restrict__ w, const f32x4* __restrict__ bias,
                                                            const int* __restrict__ kids, int64_t ld, int Kp, const int* __restrict__ seg_out,
-                                                           f32x4* __restrict__ pooled, int4* __restrict__ arg) {
+                                                           f32x4* __restrict__ pooled, int4* __restrict__ arg, f32x4* __restrict__ mean_out) {
     __shared__ f32x4 s_red[RL * 32];
     const int b = blockIdx.x, c4 = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const int r0 = seg_off[b], r1 = seg_off[b + 1];
     const int n = r1 - r0;
     if (n <= 0) {  // a cloud without voxels has no pooled rows either
-        if (rl == 0) inv_std[(int64_t)b * 32 + c4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (rl == 0) {
+            inv_std[(int64_t)b * 32 + c4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (mean_out) mean_out[(int64_t)b * 32 + c4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
         return;
     }
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -289,6 +297,15 @@ __global__ __launch_bounds__(RL * 32) void k_inorm_arp_fwd(const f32x4* __restri
 #pragma unroll
     for (int j = 0; j < 4; ++j) is[j] = 1.0f / sqrtf(var[j] + 1e-8f);
     if (rl == 0) inv_std[(int64_t)b * 32 + c4] = is;
+    const f32x4 ww = w[c4], bb = bias[c4];
+    if (mean_out) {
+        // No xhat in memory at all: the per-cloud mean is kept beside inv_std, the pooled rows normalise their children as they gather
+        // them from Y (rows this workgroup has just read: L1 / L2), and the backward kernels do the same (dd3d_arp_inorm_bwd_y).  Saves
+        // a full [rows, 128] write per level; the pooled values and winners are the same bits.
+        if (rl == 0) mean_out[(int64_t)b * 32 + c4] = mean;
+        for (int64_t o = seg_out[b] + rl; o < seg_out[b + 1]; o += RL) arp_row<true>(Y, kids, ld, Kp, o, c4, ww, bb, 1, pooled, arg, mean, is);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < CACHE; ++i) {
         int r = r0 + rl + i * RL;
@@ -298,7 +315,6 @@ __global__ __launch_bounds__(RL * 32) void k_inorm_arp_fwd(const f32x4* __restri
     // affine + ReLU + max-pool of THIS cloud's pooled rows: their children are rows of this cloud, just written by this workgroup
     // (the barrier makes them visible to it), so they come back from L2 / L1 instead of a second pass over HBM in another launch
     __syncthreads();
-    const f32x4 ww = w[c4], bb = bias[c4];
     for (int64_t o = seg_out[b] + rl; o < seg_out[b + 1]; o += RL) arp_row(xhat, kids, ld, Kp, o, c4, ww, bb, 1, pooled, arg);
 }
 
@@ -387,11 +403,16 @@ __device__ __forceinline__ void arp_inorm_bwd_slice(const f32x4* __restrict__ g_
                                                     const f32x4* __restrict__ xhat, const f32x4* __restrict__ inv_std, const f32x4* __restrict__ w,
                                                     const f32x4* __restrict__ bias, const int* __restrict__ cloud_group, f32x4* __restrict__ dY,
                                                     f32x4* __restrict__ ga_out, const f32x4* __restrict__ ga_prev, const f32x4* __restrict__ gw_extra,
-                                                    f32x4* __restrict__ part, f32x4* s_red, int b, int r0, int r1, int c4, int rl) {
+                                                    f32x4* __restrict__ part, f32x4* s_red, int b, int r0, int r1, int c4, int rl,
+                                                    const f32x4* __restrict__ mean) {
     const int n = r1 - r0;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     const f32x4 ww = w[c4], bb = bias[c4];
     const f32x4 is = inv_std[(int64_t)b * 32 + c4];  // issued with the first loads, not after the reductions (one round trip less)
+    // mean given: ``xhat`` is the norm's INPUT and a row is normalised as it is read (the bits a stored xhat row would have)
+    const bool from_y = mean != nullptr;
+    f32x4 mu = zero;
+    if (from_y) mu = mean[(int64_t)b * 32 + c4];
     f32x4 ex = zero;
     if (gw_extra) ex = gw_extra[(int64_t)(cloud_group ? cloud_group[b] : 0) * 32 + c4];
     // ga (ReLU-masked pooled gradient) and g_xhat of row i
@@ -400,6 +421,7 @@ __device__ __forceinline__ void arp_inorm_bwd_slice(const f32x4* __restrict__ g_
         const int4 a = arg[po];
         const f32x4 gp = g_pool[po];
         xh = xhat[io];
+        if (from_y) xh = (xh - mu) * is;
         ga[0] = a.x == i ? gp[0] : 0.f;
         ga[1] = a.y == i ? gp[1] : 0.f;
         ga[2] = a.z == i ? gp[2] : 0.f;
@@ -482,7 +504,8 @@ __global__ __launch_bounds__(RL * CL) __attribute__((amdgpu_waves_per_eu(4, 8)))
                                                            const int* __restrict__ seg_off, const int* __restrict__ cloud_group,
                                                            f32x4* __restrict__ dY, f32x4* __restrict__ ga_out_all, int ga_clouds,
                                                            const f32x4* __restrict__ ga_prev, const f32x4* __restrict__ gw_extra,
-                                                           f32x4* __restrict__ part /*[B][2][32] or null*/, int wave_rows) {
+                                                           f32x4* __restrict__ part /*[B][2][32] or null*/, int wave_rows,
+                                                           const f32x4* __restrict__ mean /*[B][32] or null: xhat is the norm's input*/) {
     static_assert(RL * CL == 256 && CL == 8, "four slices of eight float4 channel-lanes");
     __shared__ f32x4 s_red[4 * (RL * CL / 64) * CL];
     const int b = blockIdx.x;
@@ -501,11 +524,11 @@ __global__ __launch_bounds__(RL * CL) __attribute__((amdgpu_waves_per_eu(4, 8)))
         if (blockIdx.y) return;
         const int lane = threadIdx.x & 63;
         arp_inorm_bwd_slice<8, ARP_WAVE_CACHE, 8, true>(g_pool, arg, parent, xhat, inv_std, w, bias, cloud_group, dY, ga_out, ga_prev, gw_extra, part, s_red, b,
-                                                           r0, r1, (threadIdx.x >> 6) * 8 + (lane & 7), lane >> 3);
+                                                           r0, r1, (threadIdx.x >> 6) * 8 + (lane & 7), lane >> 3, mean);
         return;
     }
     arp_inorm_bwd_slice<RL, CACHE, CL, false>(g_pool, arg, parent, xhat, inv_std, w, bias, cloud_group, dY, ga_out, ga_prev, gw_extra, part, s_red, b, r0, r1,
-                                              blockIdx.y * CL + threadIdx.x % CL, threadIdx.x / CL);
+                                              blockIdx.y * CL + threadIdx.x % CL, threadIdx.x / CL, mean);
 }
 
 // out_w/out_b[g][c4] = sum over the clouds of group g of part[b][0/1][c4]; 16 cloud-lanes take clouds in order (a short dependent
@@ -607,7 +630,20 @@ DD3D_API int dd3d_inorm_arp_fwd(const float* Y, const int32_t* seg_off, int B, i
     if (B == 0) return 0;
     if (!Y || !seg_off || !xhat || !inv_std || !w || !b || !kids || !seg_out || !pooled || !arg) return DD3D_EARG;
     k_inorm_arp_fwd<16, 8><<<dim3(B), 512, 0, (hipStream_t)stream>>>((const f32x4*)Y, seg_off, (f32x4*)xhat, (f32x4*)inv_std, (const f32x4*)w, (const f32x4*)b,
-                                                                     kids, ld, Kp, seg_out, (f32x4*)pooled, (int4*)arg);
+                                                                     kids, ld, Kp, seg_out, (f32x4*)pooled, (int4*)arg, nullptr);
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}
+
+// dd3d_inorm_arp_fwd WITHOUT the normalised rows in memory: mean[B,128] and inv_std[B,128] are all a later pass needs next to Y itself
+// (dd3d_arp_inorm_bwd_y normalises a row as it reads it).  pooled / arg / inv_std: the same bits as dd3d_inorm_arp_fwd.
+DD3D_API int dd3d_inorm_arp_fwd_y(const float* Y, const int32_t* seg_off, int B, int C, float* mean, float* inv_std, const float* w, const float* b,
+                                  const int32_t* kids, int64_t ld, int Kp, const int32_t* seg_out, float* pooled, int32_t* arg, void* stream) {
+    if (B < 0 || C != 128 || Kp <= 0 || Kp > 8) return DD3D_EARG;
+    if (B == 0) return 0;
+    if (!Y || !seg_off || !mean || !inv_std || !w || !b || !kids || !seg_out || !pooled || !arg) return DD3D_EARG;
+    k_inorm_arp_fwd<16, 8><<<dim3(B), 512, 0, (hipStream_t)stream>>>((const f32x4*)Y, seg_off, nullptr, (f32x4*)inv_std, (const f32x4*)w, (const f32x4*)b,
+                                                                     kids, ld, Kp, seg_out, (f32x4*)pooled, (int4*)arg, (f32x4*)mean);
     DD3D_CHECK_LAUNCH();
     return 0;
 }
@@ -657,7 +693,7 @@ DD3D_API int64_t dd3d_arp_inorm_bwd_ws_bytes(int B) { return align_up64((int64_t
 // dY[M_in,128] = backward of (instance norm -> affine -> ReLU -> max pool) w.r.t. the norm's input, per cloud, in one pass.
 // gw_w/gw_b[G,128] (nullable pair): per-group affine gradients; ga_out (nullable): ReLU-masked pooled gradient;
 // ga_prev + gw_extra[G,128] (nullable pair): adds ga_prev * gw_extra[group] to the gradient w.r.t. xhat first.
-DD3D_API int dd3d_arp_inorm_bwd(const float* g_pool, const int32_t* arg, const int32_t* parent, const float* xhat, const float* inv_std,
+static int arp_inorm_bwd_launch(const float* g_pool, const int32_t* arg, const int32_t* parent, const float* xhat, const float* mean, const float* inv_std,
                                 const float* w, const float* b, int C, const int32_t* seg_off, int B, const int32_t* cloud_group,
                                 const int32_t* group_cloud_off, int G, float* dY, float* ga_out, int ga_clouds, const float* ga_prev,
                                 const float* gw_extra, float* gw_w, float* gw_b, void* ws, int64_t ws_bytes, void* stream) {
@@ -673,11 +709,31 @@ DD3D_API int dd3d_arp_inorm_bwd(const float* g_pool, const int32_t* arg, const i
         // more, smaller workgroups per CU overlap their gather chains best)
         k_arp_inorm_bwd<32, 4, 8><<<dim3(B, 4), 256, 0, st>>>((const f32x4*)g_pool, (const int4*)arg, parent, (const f32x4*)xhat, (const f32x4*)inv_std,
                                                        (const f32x4*)w, (const f32x4*)b, seg_off, cloud_group, (f32x4*)dY, (f32x4*)ga_out, ga_clouds,
-                                                       (const f32x4*)ga_prev, (const f32x4*)gw_extra, gw_w ? (f32x4*)ws : nullptr, wave_rows);
+                                                       (const f32x4*)ga_prev, (const f32x4*)gw_extra, gw_w ? (f32x4*)ws : nullptr, wave_rows,
+                                                       (const f32x4*)mean);
     }
     if (gw_w) k_cloud_group_sum<<<dim3(G, 4), 256, 0, st>>>((const f32x4*)ws, group_cloud_off, (f32x4*)gw_w, (f32x4*)gw_b);
     DD3D_CHECK_LAUNCH();
     return 0;
+}
+
+DD3D_API int dd3d_arp_inorm_bwd(const float* g_pool, const int32_t* arg, const int32_t* parent, const float* xhat, const float* inv_std,
+                                const float* w, const float* b, int C, const int32_t* seg_off, int B, const int32_t* cloud_group,
+                                const int32_t* group_cloud_off, int G, float* dY, float* ga_out, int ga_clouds, const float* ga_prev,
+                                const float* gw_extra, float* gw_w, float* gw_b, void* ws, int64_t ws_bytes, void* stream) {
+    return arp_inorm_bwd_launch(g_pool, arg, parent, xhat, nullptr, inv_std, w, b, C, seg_off, B, cloud_group, group_cloud_off, G, dY, ga_out, ga_clouds,
+                                ga_prev, gw_extra, gw_w, gw_b, ws, ws_bytes, stream);
+}
+
+// dd3d_arp_inorm_bwd over the norm's INPUT rows Y and the per-cloud mean / inv_std of dd3d_inorm_arp_fwd_y instead of stored xhat rows:
+// every output has the same bits.
+DD3D_API int dd3d_arp_inorm_bwd_y(const float* g_pool, const int32_t* arg, const int32_t* parent, const float* Y, const float* mean, const float* inv_std,
+                                  const float* w, const float* b, int C, const int32_t* seg_off, int B, const int32_t* cloud_group,
+                                  const int32_t* group_cloud_off, int G, float* dY, float* ga_out, int ga_clouds, const float* ga_prev,
+                                  const float* gw_extra, float* gw_w, float* gw_b, void* ws, int64_t ws_bytes, void* stream) {
+    if (B > 0 && !mean) return DD3D_EARG;
+    return arp_inorm_bwd_launch(g_pool, arg, parent, Y, mean, inv_std, w, b, C, seg_off, B, cloud_group, group_cloud_off, G, dY, ga_out, ga_clouds,
+                                ga_prev, gw_extra, gw_w, gw_b, ws, ws_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -178,11 +178,16 @@ class _Pass:
         L.call("dd3d_voxel_mean_fwd", L.ptr(feats), self.N, 3, L.ptr(cm.vox_off), L.ptr(cm.vox_pts), M0, c0, L.ptr(F0), st)
         Y0 = _empty((M0, 128), dev)
         L.call("dd3d_conv_fwd", L.ptr(F0), M0, 3, L.ptr(W0), 128, L.ptr(k0), ld0, 27, M0, c0, 0, L.ptr(Y0), st)
-        xh0, is0 = self.xh0, self.is0 = _empty((M0, 128), dev), _empty((B, 128), dev)
+        # The normalised rows are never written: the level keeps Y, the per-cloud mean and inv_std, and every later pass normalises a row
+        # as it reads it (same bits; one [rows, 128] write less per level).  DD3D_XHAT=1: the stored-xhat launches (measurements).
+        self.lean = lean = os.environ.get("DD3D_XHAT", "0") != "1"
+        self.Y0, self.mu0, is0 = Y0, (_empty((B, 128), dev) if lean else None), _empty((B, 128), dev)
+        self.is0 = is0
+        self._xh0 = None if lean else _empty((M0, 128), dev)
         P0, arg0 = self.P0, self.arg0 = (stash["P0"][:M1] if stash is not None else _empty((M1, 128), dev)), _empty((M1, 128), dev, _I32)
         # instance norm + affine + ReLU + max-pool of a level in one launch per cloud (the pooled rows re-read their children from cache)
-        L.call("dd3d_inorm_arp_fwd", L.ptr(Y0), L.ptr(seg1), B, 128, L.ptr(xh0), L.ptr(is0), L.ptr(w1), L.ptr(b1), L.ptr(p0), pl0, 8, L.ptr(seg2),
-               L.ptr(P0), L.ptr(arg0), st)
+        L.call("dd3d_inorm_arp_fwd_y" if lean else "dd3d_inorm_arp_fwd", L.ptr(Y0), L.ptr(seg1), B, 128, L.ptr(self.mu0 if lean else self._xh0), L.ptr(is0),
+               L.ptr(w1), L.ptr(b1), L.ptr(p0), pl0, 8, L.ptr(seg2), L.ptr(P0), L.ptr(arg0), st)
         Y1 = _empty((M1, 128), dev)
         if use_sched:
             # the 128-row kernel also takes the table in pattern order and the offsets of every tile (the 32-row one gathers through perm)
@@ -210,10 +215,12 @@ class _Pass:
                    L.ptr(Y1), st)
         else:
             L.call("dd3d_conv_fwd", L.ptr(P0), M1, 128, L.ptr(W1), 128, L.ptr(k1), ld1, 27, M1, c1, 0, L.ptr(Y1), st)
-        xh1, is1 = self.xh1, self.is1 = _empty((M1, 128), dev), _empty((B, 128), dev)
+        self.Y1, self.mu1, is1 = Y1, (_empty((B, 128), dev) if lean else None), _empty((B, 128), dev)
+        self.is1 = is1
+        self._xh1 = None if lean else _empty((M1, 128), dev)
         P1, arg1 = self.P1, self.arg1 = _empty((M2, 128), dev), _empty((M2, 128), dev, _I32)
-        L.call("dd3d_inorm_arp_fwd", L.ptr(Y1), L.ptr(seg2), B, 128, L.ptr(xh1), L.ptr(is1), L.ptr(w5), L.ptr(b5), L.ptr(p1), pl1, 8,
-               L.ptr(dp.seg_off), L.ptr(P1), L.ptr(arg1), st)
+        L.call("dd3d_inorm_arp_fwd_y" if lean else "dd3d_inorm_arp_fwd", L.ptr(Y1), L.ptr(seg2), B, 128, L.ptr(self.mu1 if lean else self._xh1), L.ptr(is1),
+               L.ptr(w5), L.ptr(b5), L.ptr(p1), pl1, 8, L.ptr(dp.seg_off), L.ptr(P1), L.ptr(arg1), st)
         logits = self.logits = _empty((B, J), dev)
         prob, dl = self.prob, self.dl = _empty((B, J), dev), _empty((B, J), dev)
         closs, self.ce = _empty((B,), dev), _empty((G,), dev)
@@ -255,7 +262,7 @@ class _Pass:
         # the ReLU-masked pooled gradients (ga) are kept for the synthetic clouds only: the second-order pass needs nothing else
         Ns = max(self.N_syn, 1)
         self.ga1, self.ga0 = _empty((Ns, 128), dev), _empty((Ns, 128), dev)
-        gY1, g_w5, g_b5 = self._arp_inorm_bwd(gP1, arg1, cm.parent(4), xh1, is1, w5, b5, seg2, M1, B, G, self.ga1, self.B_syn, True,
+        gY1, g_w5, g_b5 = self._arp_inorm_bwd(gP1, arg1, cm.parent(4), self._rows(1), is1, w5, b5, seg2, M1, B, G, self.ga1, self.B_syn, True,
                                               dY_out=None if stash is None else stash["gY1"][:M1], gb_out=None if stash is None else stash["g_b5"])
         # Two launches want the matrix cores here: the input gradient of the 128-channel convolution (main stream, everything else waits
         # for it) and its kernel gradient (side stream, only the loss value waits for it).  Side by side they share the pipe and BOTH take
@@ -279,7 +286,7 @@ class _Pass:
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 g_W1 = self._bww(P0, 128, gY1, k1, ld1, M1, gro2, seg2)
-        gY0, g_w1, g_b1 = self._arp_inorm_bwd(gP0, arg0, cm.parent(2), xh0, is0, w1, b1, seg1, M0, B, G, self.ga0, self.B_syn, True,
+        gY0, g_w1, g_b1 = self._arp_inorm_bwd(gP0, arg0, cm.parent(2), self._rows(0), is0, w1, b1, seg1, M0, B, G, self.ga0, self.B_syn, True,
                                               dY_out=None if stash is None else stash["gY0"][:M0], gb_out=None if stash is None else stash["g_b1"])
         # The first layer's kernel gradient feeds nothing but the loss VALUE either: it runs on a stream of its own next to the 128-channel
         # one (bandwidth-bound next to matrix-bound), and the main stream goes on to the matching loss of the differentiable entries and
@@ -301,16 +308,37 @@ class _Pass:
         self._side_operands = (gY1, gY0, gP1, gP0)
         return self
 
-    def _arp_inorm_bwd(self, g_pool, arg, parent, xhat, inv_std, w, b, seg, M_in, B, G, ga_out, ga_clouds, want_gw, ga_prev=None, gw_extra=None,
+    def _rows(self, level):
+        """What the backward passes of a level read: (xhat, None), or (Y, mean) when the normalised rows are not kept."""
+        if self.lean:
+            return (self.Y0, self.mu0) if level == 0 else (self.Y1, self.mu1)
+        return (self._xh0, None) if level == 0 else (self._xh1, None)
+
+    def _xhat(self, level):
+        """The normalised rows of a level as a tensor (tests and diagnostics; the step itself never materialises them)."""
+        if not self.lean:
+            return self._xh0 if level == 0 else self._xh1
+        Y, mu, inv = (self.Y0, self.mu0, self.is0) if level == 0 else (self.Y1, self.mu1, self.is1)
+        seg = self.maps[8 + level]
+        cloud = torch.bucketize(torch.arange(Y.shape[0], device=Y.device, dtype=seg.dtype), seg[1:], right=True).clamp_(max=self.B - 1).long()
+        return (Y - mu[cloud]) * inv[cloud]
+
+    xh0 = property(lambda self: self._xhat(0))
+    xh1 = property(lambda self: self._xhat(1))
+
+    def _arp_inorm_bwd(self, g_pool, arg, parent, rows, inv_std, w, b, seg, M_in, B, G, ga_out, ga_clouds, want_gw, ga_prev=None, gw_extra=None,
                        dY_out=None, gb_out=None):
         """Backward of max-pool -> ReLU -> affine -> instance norm in one pass per cloud, over the first B clouds:
-        (dY, d weight [G,128], d bias [G,128]); ``ga_out`` receives the masked pooled gradient of the first ``ga_clouds`` clouds."""
+        (dY, d weight [G,128], d bias [G,128]); ``ga_out`` receives the masked pooled gradient of the first ``ga_clouds`` clouds.
+        ``rows`` = (xhat, None) or (Y, mean): see _rows."""
         dev = self.dev
+        xhat, mean = rows
         dY = dY_out if dY_out is not None else _empty((M_in, 128), dev)
         gw_w = _empty((G, 128), dev) if want_gw else None
         gw_b = (gb_out if gb_out is not None else _empty((G, 128), dev)) if want_gw else None
         ws = L.workspace(int(L.lib.dd3d_arp_inorm_bwd_ws_bytes(B)), dev)
-        L.call("dd3d_arp_inorm_bwd", L.ptr(g_pool), L.ptr(arg), L.ptr(parent), L.ptr(xhat), L.ptr(inv_std), L.ptr(w), L.ptr(b), 128, L.ptr(seg), B,
+        head = (L.ptr(g_pool), L.ptr(arg), L.ptr(parent), L.ptr(xhat)) + ((L.ptr(mean),) if mean is not None else ())
+        L.call("dd3d_arp_inorm_bwd_y" if mean is not None else "dd3d_arp_inorm_bwd", *head, L.ptr(inv_std), L.ptr(w), L.ptr(b), 128, L.ptr(seg), B,
                L.ptr(self.cloud_group), L.ptr(self.gco), G, L.ptr(dY), L.ptr(ga_out), int(ga_clouds), L.ptr(ga_prev), L.ptr(gw_extra), L.ptr(gw_w),
                L.ptr(gw_b), L.ptr(ws), ws.numel(), L.stream())
         return dY, gw_w, gw_b
@@ -345,14 +373,14 @@ class _Pass:
         H = _empty((Ns, 128), dev)
         sl_bwd_x_call(self.dl, dp, self.cloud_group, Gsm, gst, J, 0, H, Bs, Ns)
         sl_bwd_x_call(dz, dp, None, self.Wsm, sst, J, 1, H, Bs, Ns)
-        hY1, _, _ = self._arp_inorm_bwd(H, self.arg1, cm.parent(4), self.xh1, self.is1, w5, b5, seg2, Ns, Bs, Gs, None, 0, False, self.ga1, G_w5)
+        hY1, _, _ = self._arp_inorm_bwd(H, self.arg1, cm.parent(4), self._rows(1), self.is1, w5, b5, seg2, Ns, Bs, Gs, None, 0, False, self.ga1, G_w5)
         hP0 = _empty((Ns, 128), dev)
         if Ns <= SPLIT_MAX_ROWS:  # few tiles: deal every tile's offsets over several CUs
             ws = L.workspace(int(L.lib.dd3d_conv128_split_ws_bytes(Ns)), dev)
             L.call("dd3d_conv128_split", L.ptr(hY1), Ns, L.ptr(self.W1t), L.ptr(k1), ld1, 27, Ns, m2s, 1, L.ptr(hP0), L.ptr(ws), ws.numel(), st)
         else:
             L.call("dd3d_conv_bwd_data", L.ptr(hY1), Ns, m2s, 128, L.ptr(self.W1t), 128, L.ptr(k1), ld1, 27, L.ptr(hP0), st)
-        hY0, _, _ = self._arp_inorm_bwd(hP0, self.arg0, cm.parent(2), self.xh0, self.is0, w1, b1, seg1, Ns, Bs, Gs, None, 0, False, self.ga0, G_w1)
+        hY0, _, _ = self._arp_inorm_bwd(hP0, self.arg0, cm.parent(2), self._rows(0), self.is0, w1, b1, seg1, Ns, Bs, Gs, None, 0, False, self.ga0, G_w1)
         hF0 = _empty((Ns, 3), dev)
         L.call("dd3d_conv_bwd_data", L.ptr(hY0), Ns, m1s, 128, L.ptr(W0), 3, L.ptr(k0), ld0, 27, L.ptr(hF0), st)
         dfeats = _empty((Ns, 3), dev)

@@ -205,6 +205,12 @@ int dd3d_affine_relu_pool_fwd(const float* xhat, const float* w, const float* b,
  * replaces: MinkowskiInstanceNorm + MinkowskiReLU + MinkowskiMaxPooling forward, models/MEConv.py:225-227 */
 int dd3d_inorm_arp_fwd(const float* Y, const int32_t* seg_off, int B, int C, float* xhat, float* inv_std, const float* w, const float* b,
                        const int32_t* kids, int64_t ld, int Kp, const int32_t* seg_out, float* pooled, int32_t* arg, void* stream);
+/* The same launch WITHOUT the normalised rows in memory: it writes mean[B,C] next to inv_std[B,C] instead of xhat[M,C] (one full
+ * [rows, C] write less per level); the pooled rows normalise their children as they gather them from Y, and dd3d_arp_inorm_bwd_y
+ * does the same in the backward passes.  inv_std / pooled / arg: the same bits as dd3d_inorm_arp_fwd.  Y must stay alive for the backward.
+ * replaces: MinkowskiInstanceNorm + MinkowskiReLU + MinkowskiMaxPooling forward, models/MEConv.py:225-227 (what the step runs) */
+int dd3d_inorm_arp_fwd_y(const float* Y, const int32_t* seg_off, int B, int C, float* mean, float* inv_std, const float* w, const float* b,
+                         const int32_t* kids, int64_t ld, int Kp, const int32_t* seg_out, float* pooled, int32_t* arg, void* stream);
 
 /* MinkowskiAvgPooling(kernel_size=2, stride=2) of the reference's unused model variants (models/MEConv.py:28,35,105,112,126):
  * out[v][C] = mean of the existing children of v (kids[Kp<=8][ld], -1 = none; the divisor is the number of children that exist),
@@ -233,6 +239,13 @@ int dd3d_arp_inorm_bwd(const float* g_pool, const int32_t* arg, const int32_t* p
                        const float* b, int C, const int32_t* seg_off, int B, const int32_t* cloud_group, const int32_t* group_cloud_off, int G,
                        float* dY, float* ga_out, int ga_clouds /* ga_out is written for clouds < ga_clouds only; <= 0: all */, const float* ga_prev, const float* gw_extra, float* gw_w, float* gw_b, void* ws, int64_t ws_bytes,
                        void* stream);
+/* dd3d_arp_inorm_bwd over the norm's INPUT rows Y and the per-cloud mean / inv_std of dd3d_inorm_arp_fwd_y (a row is normalised as it
+ * is read: the two roundings that a stored xhat row went through); every output has the same bits as dd3d_arp_inorm_bwd's.
+ * replaces: backward of ME.MinkowskiInstanceNorm + MinkowskiReLU + MinkowskiMaxPooling, models/MEConv.py:225-227 (what the step runs) */
+int dd3d_arp_inorm_bwd_y(const float* g_pool, const int32_t* arg, const int32_t* parent, const float* Y, const float* mean, const float* inv_std,
+                         const float* w, const float* b, int C, const int32_t* seg_off, int B, const int32_t* cloud_group,
+                         const int32_t* group_cloud_off, int G, float* dY, float* ga_out, int ga_clouds, const float* ga_prev,
+                         const float* gw_extra, float* gw_w, float* gw_b, void* ws, int64_t ws_bytes, void* stream);
 /* dd3d_arp_inorm_bwd without a workspace argument and without any allocation.  NO COUNTERPART IN THE REFERENCE: it exists for
  * callers that cannot allocate -- code under HIP-graph capture, tight serving loops, harnesses that forbid hipMalloc.  The per-cloud
  * partial sums (2 x 128 floats per cloud) live in a file-scope device array of the library, 8 MiB per GPU, held until the process

@@ -327,6 +327,60 @@ def test_one_launch_norm_act_pool_is_bitwise_the_two_launches(case):
         assert torch.equal(u, v)
 
 
+@pytest.mark.parametrize("case", CASES + [dict(B=4, pts=2500, extent=28, seed=8, dims3=True)])
+def test_norm_act_pool_without_stored_xhat_is_bitwise_the_stored_form(case):
+    """dd3d_inorm_arp_fwd_y / dd3d_arp_inorm_bwd_y (what the step runs: Y, mean and inv_std instead of normalised rows in memory) against
+    dd3d_inorm_arp_fwd / dd3d_arp_inorm_bwd: inv_std, pooled values, winners, and every backward output (first order with the affine
+    gradients, second order with ga_prev / gw_extra) bit for bit; mean = the per-cloud column mean."""
+    from dd3d_amd import _lib as L
+    coords = make_coords(**case)
+    cm = manager(coords)
+    M, Mo, B = cm.num_rows(1), cm.num_rows(2), cm.B
+    kids, ld = cm.kernel_map(1, 2, 2)
+    seg, seg_o, parent = cm.seg_off(1), cm.seg_off(2), cm.parent(2)
+    g = torch.Generator().manual_seed(19)
+    Y = (torch.randn(M, 128, generator=g) * 2 - 0.5).to(dev())
+    w = (1 + 0.2 * torch.randn(128, generator=g)).to(dev())
+    b = (0.2 * torch.randn(128, generator=g)).to(dev())
+    st = L.stream()
+    F = lambda *shape, **kw: torch.full(shape, 7.0, device=dev(), **kw)
+    xa, ia, pa, aa = F(M, 128), F(B, 128), F(Mo, 128), torch.full((Mo, 128), -3, device=dev(), dtype=torch.int32)
+    L.call("dd3d_inorm_arp_fwd", L.ptr(Y), L.ptr(seg), B, 128, L.ptr(xa), L.ptr(ia), L.ptr(w), L.ptr(b), L.ptr(kids), ld, 8, L.ptr(seg_o), L.ptr(pa),
+           L.ptr(aa), st)
+    mu, ib, pb, ab = F(B, 128), F(B, 128), F(Mo, 128), torch.full((Mo, 128), -3, device=dev(), dtype=torch.int32)
+    L.call("dd3d_inorm_arp_fwd_y", L.ptr(Y), L.ptr(seg), B, 128, L.ptr(mu), L.ptr(ib), L.ptr(w), L.ptr(b), L.ptr(kids), ld, 8, L.ptr(seg_o), L.ptr(pb),
+           L.ptr(ab), st)
+    torch.cuda.synchronize()
+    for u, v in ((ia, ib), (pa, pb), (aa, ab)):
+        assert torch.equal(u, v)
+    n = (seg[1:] - seg[:-1]).long()
+    cloud = torch.repeat_interleave(torch.arange(B, device=dev()), n)
+    ref_mu = torch.zeros(B, 128, device=dev(), dtype=torch.float64).index_add_(0, cloud, Y.double()) / n.clamp(min=1)[:, None]
+    assert float((mu.double() - ref_mu).abs().max()) < 1e-5
+    assert torch.equal((Y - mu[cloud]) * ib[cloud], xa)   # the identity the backward relies on
+    G = 2
+    gco = torch.tensor([0, B // 2, B], dtype=torch.int32, device=dev())
+    cg = (torch.arange(B, device=dev()) >= B // 2).to(torch.int32)
+    g_pool, ga_prev, gw_extra = (torch.randn(*sh, generator=g).to(dev()) for sh in ((Mo, 128), (M, 128), (G, 128)))
+    for second in (False, True):
+        outs = []
+        for lean in (False, True):
+            dY, ga, gw_w, gw_b = F(M, 128), F(M, 128), F(G, 128), F(G, 128)
+            ws = torch.empty(int(L.lib.dd3d_arp_inorm_bwd_ws_bytes(B)), dtype=torch.uint8, device=dev())
+            head = (L.ptr(g_pool), L.ptr(aa), L.ptr(parent)) + ((L.ptr(Y), L.ptr(mu)) if lean else (L.ptr(xa),))
+            L.call("dd3d_arp_inorm_bwd_y" if lean else "dd3d_arp_inorm_bwd", *head, L.ptr(ia), L.ptr(w), L.ptr(b), 128, L.ptr(seg), B, L.ptr(cg), L.ptr(gco),
+                   G, L.ptr(dY), L.ptr(ga), 0, L.ptr(ga_prev) if second else None, L.ptr(gw_extra) if second else None, L.ptr(gw_w), L.ptr(gw_b),
+                   L.ptr(ws), ws.numel(), st)
+            torch.cuda.synchronize()
+            outs.append((dY, ga, gw_w, gw_b))
+        for u, v in zip(*outs):
+            assert torch.equal(u, v)
+        assert bool(torch.isfinite(outs[1][0]).all()) and (M == B or float(outs[1][0].abs().max()) > 0)   # (single-voxel clouds: a zero gradient)
+    # a missing mean is an argument error, not a launch
+    assert L.lib.dd3d_arp_inorm_bwd_y(L.ptr(g_pool), L.ptr(aa), L.ptr(parent), L.ptr(Y), None, L.ptr(ia), L.ptr(w), L.ptr(b), 128, L.ptr(seg), B, None, None, 1,
+                                      L.ptr(outs[0][0]), None, 0, None, None, None, None, None, 0, st) == -1
+
+
 def test_sparse_linear_closed_under_differentiation():
     from dd3d_amd.ops import DensePlacement, sparse_linear
     coords = make_coords(B=6, pts=200, extent=28, seed=6)
