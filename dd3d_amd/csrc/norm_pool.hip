@@ -257,16 +257,13 @@ template <int RL, int CACHE>
 __global__ __launch_bounds__(RL * 32) void k_inorm_arp_fwd(const f32x4* __restrict__ Y, const int* __restrict__ seg_off, f32x4* __restrict__ xhat,
                                                            f32x4* __restrict__ inv_std, const f32x4* __restrict__ w, const f32x4* __restrict__ bias,
                                                            const int* __restrict__ kids, int64_t ld, int Kp, const int* __restrict__ seg_out,
-                                                           f32x4* __restrict__ pooled, int4* __restrict__ arg, f32x4* __restrict__ mean_out) {
+                                                           f32x4* __restrict__ pooled, int4* __restrict__ arg) {
     __shared__ f32x4 s_red[RL * 32];
     const int b = blockIdx.x, c4 = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const int r0 = seg_off[b], r1 = seg_off[b + 1];
     const int n = r1 - r0;
     if (n <= 0) {  // a cloud without voxels has no pooled rows either
-        if (rl == 0) {
-            inv_std[(int64_t)b * 32 + c4] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (mean_out) mean_out[(int64_t)b * 32 + c4] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
+        if (rl == 0) inv_std[(int64_t)b * 32 + c4] = (f32x4){0.f, 0.f, 0.f, 0.f};
         return;
     }
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -298,14 +295,6 @@ __global__ __launch_bounds__(RL * 32) void k_inorm_arp_fwd(const f32x4* __restri
     for (int j = 0; j < 4; ++j) is[j] = 1.0f / sqrtf(var[j] + 1e-8f);
     if (rl == 0) inv_std[(int64_t)b * 32 + c4] = is;
     const f32x4 ww = w[c4], bb = bias[c4];
-    if (mean_out) {
-        // No xhat in memory at all: the per-cloud mean is kept beside inv_std, the pooled rows normalise their children as they gather
-        // them from Y (rows this workgroup has just read: L1 / L2), and the backward kernels do the same (dd3d_arp_inorm_bwd_y).  Saves
-        // a full [rows, 128] write per level; the pooled values and winners are the same bits.
-        if (rl == 0) mean_out[(int64_t)b * 32 + c4] = mean;
-        for (int64_t o = seg_out[b] + rl; o < seg_out[b + 1]; o += RL) arp_row<true>(Y, kids, ld, Kp, o, c4, ww, bb, 1, pooled, arg, mean, is);
-        return;
-    }
 #pragma unroll
     for (int i = 0; i < CACHE; ++i) {
         int r = r0 + rl + i * RL;
@@ -316,6 +305,146 @@ __global__ __launch_bounds__(RL * 32) void k_inorm_arp_fwd(const f32x4* __restri
     // (the barrier makes them visible to it), so they come back from L2 / L1 instead of a second pass over HBM in another launch
     __syncthreads();
     for (int64_t o = seg_out[b] + rl; o < seg_out[b + 1]; o += RL) arp_row(xhat, kids, ld, Kp, o, c4, ww, bb, 1, pooled, arg);
+}
+
+
+// ---- the same level WITHOUT the normalised rows in memory (dd3d_inorm_arp_fwd_y) ----
+// The per-cloud mean is kept beside inv_std; the pooled rows normalise their children as they gather them from Y (rows this workgroup
+// has just read: L1 / L2), and the backward kernels do the same.  Saves a full [rows, 128] write per level.
+// A cloud is a chain of dependent memory round trips (row range -> rows -> two reductions -> child indices -> child rows), so what
+// counts is how many clouds a CU has in flight: 256-thread workgroups (8 row-lanes x 32 channel-lanes) instead of 512-thread ones, the
+// first pooled row's child indices loaded before the statistics, the next row's before the current one is reduced.
+// Bit-compatibility with k_inorm_fwd<16, 8>: a thread works as TWO of that kernel's 16 row-lanes (wave w, half h: lanes 4w + h and
+// 4w + 2 + h), keeps their sums apart, and the fold is that kernel's: the halves of a wave by one shuffle, the eight pair sums through
+// LDS in ascending order.  VC rows per virtual lane stay in registers (16 VC rows of the cloud); longer clouds re-read their tail.
+template <int VC>
+__device__ __forceinline__ void cloud_stats16(const f32x4* __restrict__ Y, int r0, int r1, int la, int c4, int w, int lane, f32x4* s_red,
+                                              f32x4* mean_o, f32x4* is_o) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const int n = r1 - r0;
+    f32x4 va[VC], vb[VC];
+    f32x4 sa = zero, sb = zero;
+#pragma unroll
+    for (int i = 0; i < VC; ++i) {  // clamped row index: branch-free, all loads in flight together
+        const int ra = r0 + la + i * 16, rb = ra + 2;
+        va[i] = Y[(int64_t)min(ra, r1 - 1) * 32 + c4];
+        vb[i] = Y[(int64_t)min(rb, r1 - 1) * 32 + c4];
+    }
+#pragma unroll
+    for (int i = 0; i < VC; ++i) {
+        const int ra = r0 + la + i * 16, rb = ra + 2;
+        if (ra >= r1) va[i] = zero;
+        if (rb >= r1) vb[i] = zero;
+        sa += va[i];
+        sb += vb[i];
+    }
+    for (int r = r0 + la + VC * 16; r < r1; r += 16) sa += Y[(int64_t)r * 32 + c4];
+    for (int r = r0 + la + 2 + VC * 16; r < r1; r += 16) sb += Y[(int64_t)r * 32 + c4];
+    auto fold = [&](f32x4 a, f32x4 b2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a[j] += __shfl_xor(a[j], 32, 64);
+            b2[j] += __shfl_xor(b2[j], 32, 64);
+        }
+        if (lane < 32) {
+            s_red[(2 * w) * 32 + lane] = a;
+            s_red[(2 * w + 1) * 32 + lane] = b2;
+        }
+        __syncthreads();
+        f32x4 s = s_red[c4];
+#pragma unroll 2
+        for (int j = 1; j < 8; ++j) s += s_red[j * 32 + c4];
+        __syncthreads();
+        return s;
+    };
+    const f32x4 mean = fold(sa, sb) / (float)n;
+    f32x4 qa = zero, qb = zero;
+#pragma unroll
+    for (int i = 0; i < VC; ++i) {
+        const int ra = r0 + la + i * 16, rb = ra + 2;
+        f32x4 d = va[i] - mean;
+        if (ra < r1) qa += d * d;
+        d = vb[i] - mean;
+        if (rb < r1) qb += d * d;
+    }
+    for (int r = r0 + la + VC * 16; r < r1; r += 16) {
+        f32x4 d = Y[(int64_t)r * 32 + c4] - mean;
+        qa += d * d;
+    }
+    for (int r = r0 + la + 2 + VC * 16; r < r1; r += 16) {
+        f32x4 d = Y[(int64_t)r * 32 + c4] - mean;
+        qb += d * d;
+    }
+    const f32x4 var = fold(qa, qb) / (float)n;
+    f32x4 is;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) is[j] = 1.0f / sqrtf(var[j] + 1e-8f);
+    *mean_o = mean;
+    *is_o = is;
+}
+
+template <int VCMAX>
+__global__ __launch_bounds__(256) void k_inorm_arp_fwd_y(const f32x4* __restrict__ Y, const int* __restrict__ seg_off, f32x4* __restrict__ mean_out,
+                                                         f32x4* __restrict__ inv_std, const f32x4* __restrict__ w, const f32x4* __restrict__ bias,
+                                                         const int* __restrict__ kids, int64_t ld, int Kp, const int* __restrict__ seg_out,
+                                                         f32x4* __restrict__ pooled, int4* __restrict__ arg) {
+    __shared__ f32x4 s_red[8 * 32];
+    const int b = blockIdx.x, c4 = threadIdx.x & 31, rl = threadIdx.x >> 5, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r0 = seg_off[b], r1 = seg_off[b + 1];
+    const int64_t o0 = seg_out[b], o1 = seg_out[b + 1];
+    const int n = r1 - r0;
+    if (n <= 0) {  // a cloud without voxels has no pooled rows either
+        if (rl == 0) {
+            inv_std[(int64_t)b * 32 + c4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            mean_out[(int64_t)b * 32 + c4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        return;
+    }
+    // child indices of this thread's first pooled row: in flight while the statistics run
+    int64_t o = o0 + rl;
+    int ch[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ch[k] = kids[(int64_t)min(k, Kp - 1) * ld + min(o, o1 - 1)];
+    const f32x4 ww = w[c4], bb = bias[c4];
+    f32x4 mean, is;
+    const int la = 4 * wv + (lane >> 5);
+    if (n <= 32) cloud_stats16<2>(Y, r0, r1, la, c4, wv, lane, s_red, &mean, &is);
+    else if (VCMAX <= 4 || n <= 64) cloud_stats16<4>(Y, r0, r1, la, c4, wv, lane, s_red, &mean, &is);
+    else cloud_stats16<VCMAX>(Y, r0, r1, la, c4, wv, lane, s_red, &mean, &is);
+    if (rl == 0) {
+        inv_std[(int64_t)b * 32 + c4] = is;
+        mean_out[(int64_t)b * 32 + c4] = mean;
+    }
+    // affine + ReLU + max-pool of this cloud's pooled rows (arp_row<true>, with the child indices one row ahead)
+    const float ninf = -__builtin_inff();
+    for (; o < o1; o += 8) {
+        f32x4 rows[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) rows[k] = Y[(int64_t)max(ch[k], 0) * 32 + c4];
+        int cur[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cur[k] = ch[k];
+        const int64_t on = o + 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ch[k] = kids[(int64_t)min(k, Kp - 1) * ld + min(on, o1 - 1)];
+        f32x4 best = {ninf, ninf, ninf, ninf};
+        int4 a = make_int4(-1, -1, -1, -1);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = cur[k];
+            if (k >= Kp || i < 0) continue;
+            f32x4 v = (rows[k] - mean) * is;
+            v = v * ww + bb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+            if (v[0] > best[0]) { best[0] = v[0]; a.x = i; }
+            if (v[1] > best[1]) { best[1] = v[1]; a.y = i; }
+            if (v[2] > best[2]) { best[2] = v[2]; a.z = i; }
+            if (v[3] > best[3]) { best[3] = v[3]; a.w = i; }
+        }
+        pooled[o * 32 + c4] = best;
+        arg[o * 32 + c4] = a;
+    }
 }
 
 
@@ -630,7 +759,7 @@ DD3D_API int dd3d_inorm_arp_fwd(const float* Y, const int32_t* seg_off, int B, i
     if (B == 0) return 0;
     if (!Y || !seg_off || !xhat || !inv_std || !w || !b || !kids || !seg_out || !pooled || !arg) return DD3D_EARG;
     k_inorm_arp_fwd<16, 8><<<dim3(B), 512, 0, (hipStream_t)stream>>>((const f32x4*)Y, seg_off, (f32x4*)xhat, (f32x4*)inv_std, (const f32x4*)w, (const f32x4*)b,
-                                                                     kids, ld, Kp, seg_out, (f32x4*)pooled, (int4*)arg, nullptr);
+                                                                     kids, ld, Kp, seg_out, (f32x4*)pooled, (int4*)arg);
     DD3D_CHECK_LAUNCH();
     return 0;
 }
@@ -642,8 +771,16 @@ DD3D_API int dd3d_inorm_arp_fwd_y(const float* Y, const int32_t* seg_off, int B,
     if (B < 0 || C != 128 || Kp <= 0 || Kp > 8) return DD3D_EARG;
     if (B == 0) return 0;
     if (!Y || !seg_off || !mean || !inv_std || !w || !b || !kids || !seg_out || !pooled || !arg) return DD3D_EARG;
-    k_inorm_arp_fwd<16, 8><<<dim3(B), 512, 0, (hipStream_t)stream>>>((const f32x4*)Y, seg_off, nullptr, (f32x4*)inv_std, (const f32x4*)w, (const f32x4*)b,
-                                                                     kids, ld, Kp, seg_out, (f32x4*)pooled, (int4*)arg, (f32x4*)mean);
+    static const int vc = getenv("DD3D_NORM_VC") ? atoi(getenv("DD3D_NORM_VC")) : 6;  // rows per virtual row-lane kept in registers (measurements)
+    if (vc <= 4)
+        k_inorm_arp_fwd_y<4><<<dim3(B), 256, 0, (hipStream_t)stream>>>((const f32x4*)Y, seg_off, (f32x4*)mean, (f32x4*)inv_std, (const f32x4*)w, (const f32x4*)b,
+                                                                       kids, ld, Kp, seg_out, (f32x4*)pooled, (int4*)arg);
+    else if (vc <= 6)
+        k_inorm_arp_fwd_y<6><<<dim3(B), 256, 0, (hipStream_t)stream>>>((const f32x4*)Y, seg_off, (f32x4*)mean, (f32x4*)inv_std, (const f32x4*)w, (const f32x4*)b,
+                                                                       kids, ld, Kp, seg_out, (f32x4*)pooled, (int4*)arg);
+    else
+        k_inorm_arp_fwd_y<8><<<dim3(B), 256, 0, (hipStream_t)stream>>>((const f32x4*)Y, seg_off, (f32x4*)mean, (f32x4*)inv_std, (const f32x4*)w, (const f32x4*)b,
+                                                                       kids, ld, Kp, seg_out, (f32x4*)pooled, (int4*)arg);
     DD3D_CHECK_LAUNCH();
     return 0;
 }
