@@ -41,15 +41,15 @@ __device__ __forceinline__ int pattern_bucket(unsigned key) {
     return (int)(out << 8 | plane);
 }
 
-// keys[i] = pattern of row i; hist[b] += rows of bucket b (one LDS histogram per workgroup of 1024 rows -- one row per thread, so that a
-// launch of 87 k rows already spreads over 86 CUs -- then one global add per bucket it met)
+// keys[i] = pattern of row i; hist[b] += rows of bucket b (one LDS histogram per workgroup -- one row per thread, so that a
+// launch of 87 k rows already spreads over many CUs -- then one global add per bucket it met)
 __global__ __launch_bounds__(1024) void k_row_keys(const int* __restrict__ nbr, int64_t ld, int K, int M_bound, const int* __restrict__ m_dev,
                                                    unsigned* __restrict__ keys, int* __restrict__ hist) {
     __shared__ int s_h[NB];
     const int M = m_dev ? min(*m_dev, M_bound) : M_bound;
-    const int i0 = blockIdx.x * 1024;
+    const int nt = blockDim.x, i0 = blockIdx.x * nt;  // one row per thread
     if (i0 >= M) return;
-    for (int b = threadIdx.x; b < NB; b += 1024) s_h[b] = 0;
+    for (int b = threadIdx.x; b < NB; b += nt) s_h[b] = 0;
     __syncthreads();
     const int i = i0 + threadIdx.x;
     if (i < M) {
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(1024) void k_row_keys(const int* __restrict__ nbr, 
         atomicAdd(&s_h[pattern_bucket(key)], 1);
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < NB; b += 1024)
+    for (int b = threadIdx.x; b < NB; b += nt)
         if (s_h[b]) atomicAdd(&hist[b], s_h[b]);
 }
 
@@ -400,7 +400,12 @@ DD3D_API int dd3d_conv_schedule(const int32_t* nbr, int64_t ld, int K, int64_t M
     hipStream_t st = (hipStream_t)stream;
     const unsigned nwg = (unsigned)ceil_div64(M, 4096);
     DD3D_HIP(hipMemsetAsync(w.hist, 0, 2 * NB * 4, st));
-    k_row_keys<<<dim3((unsigned)ceil_div64(M, 1024)), 1024, 0, st>>>(nbr, ld, K, (int)M, m_dev, w.keys, w.hist);
+    // 512-thread workgroups: in the step this kernel starts beside the first layer's convolution, whose workgroups leave less than a
+    // quarter of a CU's registers free, and a 1024-thread workgroup waited for a whole CU to drain (42 us instead of 7; cfg2 step 1.243 ->
+    // 1.223 ms, 256 threads: 1.229).  The same change to k_row_scatter made no difference.  DD3D_ROWKEYS_T: measurements.
+    static const int rk_t = getenv("DD3D_ROWKEYS_T") ? atoi(getenv("DD3D_ROWKEYS_T")) : 512;
+    if (rk_t < 64 || rk_t > 1024 || rk_t % 64) return DD3D_EARG;
+    k_row_keys<<<dim3((unsigned)ceil_div64(M, rk_t)), rk_t, 0, st>>>(nbr, ld, K, (int)M, m_dev, w.keys, w.hist);
     const bool refine = M >= REFINE_LAUNCH_MIN;  // M may be a bound: the kernels take the second level only when the TRUE count reaches REFINE_MIN
     // (with a second sort level the table is not permuted: dd3d_conv128_ordered then gathers it through perm, told by tile_mask bit 31)
     k_row_scatter<<<dim3(nwg), 1024, 0, st>>>(w.keys, (int)M, m_dev, w.hist, w.fill, w.ends, perm, w.sorted_keys, refine ? w.perm_tmp : nullptr,
