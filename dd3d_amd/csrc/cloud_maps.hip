@@ -407,19 +407,108 @@ __device__ __forceinline__ void k3_offset(int k, int ts, int* d0, int* d1, int* 
 }
 
 // ---- pass B: rebuild the tables and emit every map at its global rows ----
+// The scan folded into pass B (cnt != null): every cloud's workgroup sums the counts of the clouds before it itself (B / 256 coalesced L2
+// reads per thread and level) and folds its group's minimum corner from the per-cloud corners, instead of waiting for a one-workgroup
+// scan kernel between the two passes -- five dependent memory round trips, ~15 us of an otherwise idle GPU per step.  Who writes what:
+// cloud b its own seg[l][b]; the last cloud also seg[l][B] and counts[l]; the cloud that STARTS group g (group_cloud_off[g] == b; the
+// last cloud for groups that start at B) writes gro[l][g] and gmin[g].  cloud_group[b] must be the group whose range holds b.
+struct ScanIn {
+    const int* cnt;         // [3][B] voxel counts of pass A (null: seg / gmin come from k_cloud_scan)
+    const int* cmin;        // [3][B] per-cloud minimum corners of pass A (null without dense placement)
+    const int* gco;         // [G+1] group_cloud_off (null: no per-group outputs, one group)
+    const int* gmin_floor;  // [G][3] or null
+    int* seg;               // [3][B+1]
+    int* counts;            // [3]
+    int* gro;               // [3][G+1] or null
+    int* gmin;              // [G][3] or null
+    int G;
+};
+
 template <int NMAX>
 __global__ __launch_bounds__(CT) void k_cloud_emit(const float4* __restrict__ coords, const int* __restrict__ pt_off, int B,
                                                    const int* __restrict__ cloud_group, const int* __restrict__ seg /*[3][B+1]*/, CloudOut o,
-                                                   int* err) {
+                                                   int* err, ScanIn si) {
     constexpr int HC = CloudSmem<NMAX>::HC, HC2 = CloudSmem<NMAX>::HC2;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     CloudSmem<NMAX>& S = *reinterpret_cast<CloudSmem<NMAX>*>(smem_raw);
+    __shared__ int s_scan[4 * 6];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int p0 = pt_off[b];
+    int r1, r2, r4, gm0 = 0, gm1 = 0, gm2 = 0;
+    if (si.cnt) {
+        const int big = 0x7F7F7F7F;
+        const int g = cloud_group ? cloud_group[b] : 0;
+        int v[6] = {0, 0, 0, big, big, big};
+        for (int i = tid; i < b; i += CT) {
+            v[0] += si.cnt[i];
+            v[1] += si.cnt[B + i];
+            v[2] += si.cnt[2 * B + i];
+        }
+        if (si.cmin) {  // minimum corner of this cloud's group (its clouds are contiguous: group_cloud_off; without it, one group)
+            const int c0 = si.gco ? si.gco[g] : 0, c1 = si.gco ? si.gco[g + 1] : B;
+            for (int i = c0 + tid; i < c1; i += CT) {
+                v[3] = min(v[3], si.cmin[i]);
+                v[4] = min(v[4], si.cmin[B + i]);
+                v[5] = min(v[5], si.cmin[2 * B + i]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) v[q] = wave_sum_i(v[q]);
+#pragma unroll
+        for (int q = 3; q < 6; ++q)
+#pragma unroll
+            for (int sh = 32; sh > 0; sh >>= 1) v[q] = min(v[q], __shfl_xor(v[q], sh, 64));
+        if ((tid & 63) == 0)
+#pragma unroll
+            for (int q = 0; q < 6; ++q) s_scan[(tid >> 6) * 6 + q] = v[q];
+        lds_barrier();
+#pragma unroll
+        for (int q = 0; q < 3; ++q) v[q] = s_scan[q] + s_scan[6 + q] + s_scan[12 + q] + s_scan[18 + q];
+#pragma unroll
+        for (int q = 3; q < 6; ++q) v[q] = min(min(s_scan[q], s_scan[6 + q]), min(s_scan[12 + q], s_scan[18 + q]));
+        r1 = v[0]; r2 = v[1]; r4 = v[2];
+        if (si.cmin && si.gmin_floor) {
+            v[3] = min(v[3], si.gmin_floor[g * 3 + 0]);
+            v[4] = min(v[4], si.gmin_floor[g * 3 + 1]);
+            v[5] = min(v[5], si.gmin_floor[g * 3 + 2]);
+        }
+        gm0 = v[3]; gm1 = v[4]; gm2 = v[5];
+        const bool last = b == B - 1;
+        if (tid < 3) {
+            const int r = tid == 0 ? r1 : tid == 1 ? r2 : r4;
+            si.seg[tid * (B + 1) + b] = r;
+            if (last) {
+                const int tot = r + si.cnt[tid * B + b];
+                si.seg[tid * (B + 1) + B] = tot;
+                si.counts[tid] = tot;
+            }
+        }
+        if (si.gco) {  // per-group outputs of the groups that start at this cloud (or, for the last cloud, behind it)
+            for (int q = tid; q <= si.G; q += CT) {
+                const int start = si.gco[q];
+                const bool mine = start == b, tail = last && start >= B;
+                if (!mine && !tail) continue;
+                if (si.gro) {
+                    si.gro[q] = mine ? r1 : r1 + si.cnt[b];
+                    si.gro[(si.G + 1) + q] = mine ? r2 : r2 + si.cnt[B + b];
+                    si.gro[2 * (si.G + 1) + q] = mine ? r4 : r4 + si.cnt[2 * B + b];
+                }
+                if (si.gmin && q < si.G) {
+                    const bool own = mine && q == g;  // a group that starts here but is not this cloud's is empty
+                    for (int a = 0; a < 3; ++a)
+                        si.gmin[q * 3 + a] = own ? (a == 0 ? gm0 : a == 1 ? gm1 : gm2) : (si.gmin_floor ? si.gmin_floor[q * 3 + a] : big);
+                }
+            }
+        } else if (si.gmin && b == 0 && tid < 3) {
+            si.gmin[tid] = tid == 0 ? gm0 : tid == 1 ? gm1 : gm2;
+        }
+    }
     int n;
     Cells cells1, cells2;
     const CloudCounts c = build_cloud<NMAX>(S, coords, p0, pt_off[b + 1] - p0, b, err, &n, &cells1, &cells2);
-    const int r1 = seg[b], r2 = seg[(B + 1) + b], r4 = seg[2 * (B + 1) + b];
+    if (!si.cnt) {
+        r1 = seg[b]; r2 = seg[(B + 1) + b]; r4 = seg[2 * (B + 1) + b];
+    }
 
     // stride 1: coordinates, first point, inverse map
     for (int v = tid; v < c.m1; v += CT) {
@@ -514,7 +603,7 @@ __global__ __launch_bounds__(CT) void k_cloud_emit(const float4* __restrict__ co
     // dense() placement of the stride-4 voxels: site = flat index relative to the group's minimum corner
     if (o.site) {
         const int g = cloud_group ? cloud_group[b] : 0;
-        const int m0 = o.gmin[g * 3 + 0], m1 = o.gmin[g * 3 + 1], m2 = o.gmin[g * 3 + 2];
+        const int m0 = si.cnt ? gm0 : o.gmin[g * 3 + 0], m1 = si.cnt ? gm1 : o.gmin[g * 3 + 1], m2 = si.cnt ? gm2 : o.gmin[g * 3 + 2];
         for (int t = tid; t < c.m4; t += CT) {
             const int4 u = S.U4[t];
             const int a = (u.y - m0) / 4, d = (u.z - m1) / 4, e = (u.w - m2) / 4;
@@ -540,9 +629,18 @@ int launch_cloud_maps(const float4* coords, const int* pt_off, int B, const int*
         DD3D_HIP(hipFuncSetAttribute((const void*)k_cloud_count<NMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         DD3D_HIP(hipFuncSetAttribute((const void*)k_cloud_emit<NMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     }
+    // The scan runs inside pass B (see ScanIn) unless the per-group corners need the global-atomic path (more groups than
+    // GMIN_LDS_GROUPS) or dense placement comes without group_cloud_off (the groups' clouds are then not known to be contiguous).
+    static const bool fuse_env = !(getenv("DD3D_CLOUD_SCAN_KERNEL") && atoi(getenv("DD3D_CLOUD_SCAN_KERNEL")));  // 1: the separate scan kernel (measurements)
+    const bool fuse = fuse_env && (!gmin || (cmin && (group_cloud_off || G == 1)));
+    ScanIn si = {};
+    if (fuse) {
+        si.cnt = cnt; si.cmin = gmin ? cmin : nullptr; si.gco = group_cloud_off; si.gmin_floor = gmin_floor; si.seg = seg; si.counts = counts;
+        si.gro = gro; si.gmin = gmin; si.G = G;
+    }
     k_cloud_count<NMAX><<<dim3(B), CT, smem_count, st>>>(coords, pt_off, B, cloud_group, cnt, gmin, err, cmin, o.vox_at, o.E0 * o.E1 * o.E2);
-    k_cloud_scan<<<1, 1024, 0, st>>>(cnt, B, seg, counts, group_cloud_off, G, gro, cmin, cloud_group, gmin, gmin_floor);
-    k_cloud_emit<NMAX><<<dim3(B), CT, smem, st>>>(coords, pt_off, B, cloud_group, seg, o, err);
+    if (!fuse) k_cloud_scan<<<1, 1024, 0, st>>>(cnt, B, seg, counts, group_cloud_off, G, gro, cmin, cloud_group, gmin, gmin_floor);
+    k_cloud_emit<NMAX><<<dim3(B), CT, smem, st>>>(coords, pt_off, B, cloud_group, seg, o, err, si);
     DD3D_CHECK_LAUNCH();
     return 0;
 }
