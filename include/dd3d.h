@@ -96,7 +96,9 @@ int dd3d_gather_clouds(const float* pool_xyz, const int32_t* pool_off, int n_poo
  * vox_at[E0*E1*E2][B]; pass site = NULL to skip); optional group_row_off[3][G+1] = first row of every group of clouds at the three
  * strides, from group_cloud_off[G+1] (nullable pair); optional gmin_floor[G,3]: an upper bound of every group's minimum corner -- the
  * corner of the clouds of the group that are NOT in this call (a rank that holds part of a class's real batch: dense() places by the
- * minimum over the whole batch, MEConv.py:251-254).  *err_dev |= 1 batch column of a point != its cloud, |= 2 voxel outside the
+ * minimum over the whole batch, MEConv.py:251-254).  With group_cloud_off given, cloud_group[b] must be the group whose range
+ * [group_cloud_off[g], group_cloud_off[g+1]) holds cloud b (the groups' clouds are contiguous): the count scan then runs inside the
+ * second pass (two launches instead of three).  *err_dev |= 1 batch column of a point != its cloud, |= 2 voxel outside the
  * dense extent, |= 8 a cloud has more than max_points points.
  * replaces: x.sparse(), the coordinate maps of both MinkowskiConvolution and both MinkowskiMaxPooling layers and the index math of
  * SparseTensor.dense(), models/MEConv.py:247,224,227,250-254 */
