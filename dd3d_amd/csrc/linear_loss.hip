@@ -267,6 +267,7 @@ __global__ __launch_bounds__(256) void k_cls_head(const float* __restrict__ part
                                                   float* __restrict__ prob, float* __restrict__ dlogits, float* __restrict__ cloud_loss,
                                                   float* __restrict__ loss_g, float* __restrict__ bias_grad /*[G][J] or null*/, int* __restrict__ counter) {
     __shared__ int s_last;
+    __shared__ float s_z[64 * 16];  // the workgroup's logits when J <= 16 (the softmax reads them back from LDS instead of through L2)
     const int g = blockIdx.y, tid = threadIdx.x;
     const int b0 = group_cloud_off[g], b1 = group_cloud_off[g + 1];
     const int c0 = b0 + blockIdx.x * 64, c1 = min(c0 + 64, b1);
@@ -276,22 +277,26 @@ __global__ __launch_bounds__(256) void k_cls_head(const float* __restrict__ part
         float s = 0.f;
         int v = seg_off[b];
         const int v1 = seg_off[b + 1];
-        for (; v + 8 <= v1; v += 8) {
-            float x[8];
+        // sixteen rows in flight, clamped index and masked add (a cloud has ~12 stride-4 voxels: one round trip instead of a batch of
+        // eight and a one-by-one tail); the adds run in row order as before
+        for (; v < v1; v += 16) {
+            float x[16];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) x[q] = part[(int64_t)(v + q) * J + j];
+            for (int q = 0; q < 16; ++q) x[q] = part[(int64_t)min(v + q, v1 - 1) * J + j];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) s += x[q];
+            for (int q = 0; q < 16; ++q)
+                if (v + q < v1) s += x[q];
         }
-        for (; v < v1; ++v) s += part[(int64_t)v * J + j];
-        logits[(int64_t)b * J + j] = bias ? s + bias[j] : s;
+        const float zz = bias ? s + bias[j] : s;
+        logits[(int64_t)b * J + j] = zz;
+        if (J <= 16) s_z[t] = zz;
     }
     __threadfence_block();
     __syncthreads();
     if (tid < c1 - c0) {  // k_softmax_ce: one cloud per thread
         const int b = c0 + tid;
         const float inv = 1.0f / (float)max(b1 - b0, 1);
-        const float* z = logits + (int64_t)b * J;
+        const float* z = J <= 16 ? s_z + tid * J : logits + (int64_t)b * J;
         float m = z[0];
         for (int j = 1; j < J; ++j) m = fmaxf(m, z[j]);
         float se = 0.f;
