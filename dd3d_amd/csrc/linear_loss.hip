@@ -84,14 +84,14 @@ __global__ void k_sl_fwd_sum(const float* __restrict__ part, const int* __restri
     float s = 0.f;
     int v = seg_off[b];
     const int v1 = seg_off[b + 1];
-    for (; v + 8 <= v1; v += 8) {  // eight loads in flight, added in row order (same sum, bit for bit, as one by one)
-        float x[8];
+    for (; v < v1; v += 16) {  // sixteen loads in flight (clamped index, masked add), added in row order: same sum, bit for bit, as one by one
+        float x[16];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) x[q] = part[(int64_t)(v + q) * J + j];
+        for (int q = 0; q < 16; ++q) x[q] = part[(int64_t)min(v + q, v1 - 1) * J + j];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) s += x[q];
+        for (int q = 0; q < 16; ++q)
+            if (v + q < v1) s += x[q];
     }
-    for (; v < v1; ++v) s += part[(int64_t)v * J + j];
     out[t] = bias ? s + bias[j] : s;
 }
 
