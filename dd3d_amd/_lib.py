@@ -42,6 +42,7 @@ _SIGS = {
     "dd3d_segment_offsets": (I32, [P, P, I64, I32, P, P, P]),
     "dd3d_dense_sites": (I32, [P, P, I64, P, I32, I32, I32, I32, I32, I32, P, P, P, P, P]),
     "dd3d_gather_clouds": (I32, [P, P, I32, P, I32, I32, I64, I32, I64, F32, P, P, P, P, P, P]),
+    "dd3d_assemble_batch": (I32, [P, I64, I32, P, I32, F32, F32, I32, F32, P, P, I32, P, I32, I32, I64, I32, I64, P, P, P, P, P, P, I32, P]),
     "dd3d_cloud_maps_max_points": (I32, []),
     "dd3d_cloud_maps_ws_bytes": (I64, [I32]),
     "dd3d_cloud_maps": (I32, [P, P, I32, I32, I64, P, I32, I32, I32, I32] + [P] * 17 + [I64, P, P, P, P, P, P, P, P, I64, P]),

@@ -382,6 +382,89 @@ __global__ void k_gather_clouds(const float* __restrict__ pool_xyz, const int* _
     }
 }
 
+// The head of a step in ONE launch (dd3d_assemble_batch): workgroups [0, syn_blocks) clamp the learnable points and write the owned
+// synthetic clouds into the head of the merged batch (what k_syn_head of linear_loss.hip does, point for point), workgroup syn_blocks + b
+// gathers sampled cloud b behind them (k_gather_clouds) after summing the point counts of the clouds before it ITSELF (what the
+// one-workgroup k_cloud_offsets did in a launch of its own: B / 128 dependent index -> offset reads per thread, from L2), and the
+// first gather workgroup clears `zero_words` ints at `zero` (the map builder's per-step count / error words).  Same outputs, bit for bit.
+__global__ __launch_bounds__(128) void k_assemble_batch(float* __restrict__ xyz, int64_t n_points, int npts, const int* __restrict__ dest_cloud, int do_clamp,
+                                                        float lo, float hi, int zero_first, float quant, int syn_blocks,
+                                                        const float* __restrict__ pool_xyz, const int* __restrict__ pool_off, const int* __restrict__ ids,
+                                                        int n_pool, int B, int cap, int64_t bound, int cloud_base, int point_base,
+                                                        float4* __restrict__ coords, float* __restrict__ feats, int* __restrict__ pt_off /* + cloud_base */,
+                                                        int* __restrict__ n_dev, int* err, int* __restrict__ zero, int zero_words) {
+    __shared__ int s_w[2];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < syn_blocks) {
+        float* cf = (float*)coords;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {  // (k_syn_head runs 256 points per workgroup)
+            const int64_t p = (int64_t)blockIdx.x * 256 + half * 128 + tid;
+            if (p >= n_points) return;
+            float v[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                float x = xyz[p * 3 + a];
+                if (do_clamp) {
+                    x = x < lo ? lo : x;
+                    x = x > hi ? hi : x;
+                }
+                if (zero_first && a == 0) x = 0.f;
+                v[a] = x;
+                xyz[p * 3 + a] = x;
+            }
+            const int64_t c = p / npts;
+            const int d = dest_cloud ? dest_cloud[c] : (int)c;
+            if (d < 0) continue;
+            const int64_t r = (int64_t)d * npts + (p - c * npts);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                cf[r * 4 + 1 + a] = v[a] / quant;
+                feats[r * 3 + a] = v[a];
+            }
+        }
+        return;
+    }
+    const int b = blockIdx.x - syn_blocks;
+    if (b == 0)
+        for (int i = tid; i < zero_words; i += 128) zero[i] = 0;
+    // points of the clouds before this one (an index outside the pool: an empty cloud, flagged by the cloud's own workgroup)
+    int sum = 0;
+    for (int i = tid; i < b; i += 128) {
+        const int id = ids[i];
+        if (id >= 0 && id < n_pool) sum += min(pool_off[id + 1] - pool_off[id], cap);
+    }
+    sum = wave_sum_i(sum);
+    if ((tid & 63) == 0) s_w[tid >> 6] = sum;
+    __syncthreads();
+    const int start = point_base + s_w[0] + s_w[1];
+    const int id = ids[b];
+    const bool ok = id >= 0 && id < n_pool;
+    const int cnt = ok ? min(pool_off[id + 1] - pool_off[id], cap) : 0;
+    if (tid == 0) {
+        pt_off[b] = start;
+        if (!ok) atomicOr(err, 4);  // sampled index outside the pool: the cloud comes out empty
+        if (b == B - 1) {
+            int total = start + cnt;
+            if (total > bound) {
+                atomicOr(err, 4);  // the caller's bound is too small: rows beyond it are dropped
+                total = (int)bound;
+            }
+            pt_off[B] = total;
+            *n_dev = total;
+        }
+    }
+    if (!ok) return;
+    const int dst0 = (int)min((int64_t)start, bound), n = (int)min((int64_t)start + cnt, bound) - dst0;
+    const float* src = pool_xyz + (int64_t)pool_off[id] * 3;
+    for (int i = tid; i < n; i += 128) {
+        const float x = src[i * 3 + 0], y = src[i * 3 + 1], z = src[i * 3 + 2];
+        coords[dst0 + i] = make_float4((float)(cloud_base + b), x / quant, y / quant, z / quant);  // create_input_batch: coords / quantization_size
+        float* f = feats + (int64_t)(dst0 + i) * 3;
+        f[0] = x; f[1] = y; f[2] = z;
+    }
+}
+
 inline dim3 grid1(int64_t n) { return dim3((unsigned)ceil_div64(n > 0 ? n : 1, TB)); }
 
 int large_exclusive_scan(const int* in, int64_t n, int* out, int* bsum /*[ceil(n/1024)]*/, hipStream_t st) {
@@ -574,6 +657,31 @@ DD3D_API int dd3d_gather_clouds(const float* pool_xyz, const int32_t* pool_off, 
     int32_t* po = pt_off + cloud_base;
     k_cloud_offsets<<<1, 1024, 0, st>>>(pool_off, ids, B, n_pool, cap, bound, (int)point_base, po, n_dev, err_dev);
     if (B > 0) k_gather_clouds<<<dim3(B), 128, 0, st>>>(pool_xyz, pool_off, ids, n_pool, po, B, cloud_base, quant, (float4*)coords, feats);
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}
+
+// dd3d_syn_head (linear_loss.hip) + dd3d_gather_clouds in ONE launch, the cloud offsets computed by the gathering workgroups
+// themselves, plus an optional clear of `zero_words` ints at `zero` (nullable): what a captured step runs first.  The synthetic clouds
+// are the first syn_clouds_owned clouds of the batch (cloud_base = their number, point_base = their points).  Same outputs as the two
+// calls, bit for bit.
+DD3D_API int dd3d_assemble_batch(float* xyz, int64_t n_syn_clouds, int npts, const int32_t* dest_cloud, int do_clamp, float lo, float hi, int zero_first,
+                                 float quant, const float* pool_xyz, const int32_t* pool_off, int n_pool, const int32_t* ids, int B, int cap, int64_t bound,
+                                 int cloud_base, int64_t point_base, float* coords, float* feats, int32_t* pt_off, int32_t* n_dev, int32_t* err_dev,
+                                 int32_t* zero, int zero_words, void* stream) {
+    if (B < 0 || n_pool < 0 || cap < 0 || bound < 0 || bound >= (1ll << 31) || cloud_base < 0 || point_base < 0 || point_base > bound || !(quant > 0.f) || !pt_off ||
+        !n_dev || !err_dev || n_syn_clouds < 0 || npts <= 0 || zero_words < 0 || (zero_words > 0 && !zero))
+        return DD3D_EARG;
+    if (B > 0 && (!pool_xyz || !pool_off || !ids || !coords || !feats)) return DD3D_EARG;
+    const int64_t n = n_syn_clouds * npts;
+    if (n > 0 && (!xyz || !coords || !feats)) return DD3D_EARG;
+    if (B == 0)  // no real clouds: the two-call path handles the degenerate batch (offsets of an empty sample, nothing to gather)
+        return DD3D_EARG;
+    const int64_t syn_blocks = ceil_div64(n, 256);
+    if (syn_blocks + B >= (1ll << 31)) return DD3D_ESIZE;
+    k_assemble_batch<<<dim3((unsigned)(syn_blocks + B)), 128, 0, (hipStream_t)stream>>>(xyz, n, npts, dest_cloud, do_clamp, lo, hi, zero_first, quant, (int)syn_blocks,
+                                                                                      pool_xyz, pool_off, ids, n_pool, B, cap, bound, cloud_base, (int)point_base,
+                                                                                      (float4*)coords, feats, pt_off + cloud_base, n_dev, err_dev, zero, zero_words);
     DD3D_CHECK_LAUNCH();
     return 0;
 }

@@ -92,7 +92,7 @@ class _Pass:
     pass is the same kernels called on the first ``B_syn`` clouds with the prefix's row counts (``seg_off[B_syn]``, on the device)."""
 
     def __init__(self, net, coords, B, G, cloud_group, group_cloud_off, B_syn, N_syn, side, n_dev=None, static=False, pt_off=None, max_points=0,
-                 extent=None, side2=None, stash=None, Gs=None, dl_scale=None, gmin_floor=None, max_per_group=0):
+                 extent=None, side2=None, stash=None, Gs=None, dl_scale=None, gmin_floor=None, max_per_group=0, flags=None):
         """Phase 1 (no host sync): every coordinate map, enqueued on the current stream.
         ``static``: never read a size back -- every launch covers its bound and takes the true row count from the device
         (``n_dev`` = number of valid rows of ``coords``), so the pass can be captured into a HIP graph."""
@@ -110,7 +110,8 @@ class _Pass:
         if pt_off is not None and 0 < max_points <= int(L.lib.dd3d_cloud_maps_max_points()):
             # clouds small enough for LDS: the whole pyramid (+ dense placement) in three launches
             cm = CloudCoordinateManager(coords, pt_off, B, max_points, extent, cloud_group, G, group_cloud_off,
-                                        out=None if stash is None else {k: stash[k] for k in ("nbr1", "nbr2", "gro")}, gmin_floor=gmin_floor)
+                                        out=None if stash is None else {k: stash[k] for k in ("nbr1", "nbr2", "gro")}, gmin_floor=gmin_floor,
+                                        flags=flags)
         else:
             if stash is not None or gmin_floor is not None:
                 raise ValueError("the deferred-loss mode and split real batches need the cloud-local map builder (clouds of at most 1024 points)")
@@ -770,6 +771,7 @@ class FusedDistiller:
         st.pt_off[:Bs + 1] = self.syn_pt_off
         st.n = torch.zeros(1, dtype=_I32, device=dev)
         st.err = torch.zeros(1, dtype=_I32, device=dev)
+        st.flags = torch.zeros(CloudCoordinateManager.MAX_LEVELS + 1, dtype=_I32, device=dev)   # the map builder's count / error words (cleared by dd3d_assemble_batch)
         rl = torch.tensor(np.repeat(self.real_classes, sizes), device=dev, dtype=_I32)
         rg = torch.tensor(np.repeat(np.arange(self.Gr), sizes), device=dev, dtype=_I32)
         rgco = torch.tensor(np.cumsum(sizes), device=dev, dtype=_I32)
@@ -884,7 +886,8 @@ class FusedDistiller:
         transposed_kernel(net.features[4].kernel)
         p = _Pass(net, mb["coordinates"], int(mb["num_clouds"]), G + self.Gr, mb["cloud_group"], mb["group_cloud_off"], G * ipc, G * ipc * npts,
                   self.stream_side, mb.get("n_dev"), static, mb.get("pt_off"), npts, extent, self.stream_side2, stash, Gs=G,
-                  dl_scale=self.dl_scale, gmin_floor=mb.get("gmin_floor"), max_per_group=max(ipc, int(mb.get("max_per") or mb["num_clouds"])))
+                  dl_scale=self.dl_scale, gmin_floor=mb.get("gmin_floor"), max_per_group=max(ipc, int(mb.get("max_per") or mb["num_clouds"])),
+                  flags=mb.get("flags"))
         p.run(mb["features"], mb["labels"], defer=stash is not None)
         gw_syn, gw_real = [None if t is None else t[:G] for t in p.gw], [None if t is None else t[G:] for t in p.gw]
         # Only these entries of gw_syn depend on the synthetic points: IN weights, classifier weight and bias.  For the
@@ -970,18 +973,30 @@ class FusedDistiller:
         # clamp + the owned synthetic clouds into the head of the merged batch (coordinates = xyz / quantization_size, features = xyz:
         # the same tensor twice, Mnist2D.py:84-92), one launch
         cr = self.clamp_range
-        L.call("dd3d_syn_head", L.ptr(self.image_syn), self.image_syn.shape[0], self.num_points, L.ptr(self.dest_cloud), int(cr is not None),
-               float(cr[0]) if cr else 0.0, float(cr[1]) if cr else 0.0, int(self.zero_first_axis), self.quant, L.ptr(st.coords), L.ptr(st.feats),
-               L.stream())
+        # DD3D_ASSEMBLE (default): clamp + synthetic head + real-batch gather + the map builder's cleared flag words in ONE launch
+        # (dd3d_assemble_batch: the gathering workgroups compute their own offsets); 0: the separate launches
+        one = os.environ.get("DD3D_ASSEMBLE", "1") != "0" and st.B > 0
+        lds_maps = 0 < self.num_points <= int(L.lib.dd3d_cloud_maps_max_points())
+        flags = st.flags if one and lds_maps else None
+        if one:
+            L.call("dd3d_assemble_batch", L.ptr(self.image_syn), self.image_syn.shape[0], self.num_points, L.ptr(self.dest_cloud), int(cr is not None),
+                   float(cr[0]) if cr else 0.0, float(cr[1]) if cr else 0.0, int(self.zero_first_axis), self.quant, L.ptr(st.pool_xyz), L.ptr(st.pool_off),
+                   st.n_pool, L.ptr(st.ids), st.B, self.num_points, st.bound_total, Bs, Ns, L.ptr(st.coords), L.ptr(st.feats), L.ptr(st.pt_off), L.ptr(st.n),
+                   L.ptr(st.err), L.ptr(st.flags), int(st.flags.numel()), L.stream())
+        else:
+            L.call("dd3d_syn_head", L.ptr(self.image_syn), self.image_syn.shape[0], self.num_points, L.ptr(self.dest_cloud), int(cr is not None),
+                   float(cr[0]) if cr else 0.0, float(cr[1]) if cr else 0.0, int(self.zero_first_axis), self.quant, L.ptr(st.coords), L.ptr(st.feats),
+                   L.stream())
         # (forked behind the first kernel of the step: a fork from a capture stream that has no node yet crashed hipStreamEndCapture)
         if self.defer and self._pending is not None:
             self.stream_defer.wait_stream(torch.cuda.current_stream(self.device))
             with L.ws_scope(self._scope + "d%d" % parity):
                 self._run_deferred(self._pending)
-        L.call("dd3d_gather_clouds", L.ptr(st.pool_xyz), L.ptr(st.pool_off), st.n_pool, L.ptr(st.ids), st.B, self.num_points, st.bound_total,
-               Bs, Ns, self.quant, L.ptr(st.coords), L.ptr(st.feats), L.ptr(st.pt_off), L.ptr(st.n), L.ptr(st.err), L.stream())
+        if not one:
+            L.call("dd3d_gather_clouds", L.ptr(st.pool_xyz), L.ptr(st.pool_off), st.n_pool, L.ptr(st.ids), st.B, self.num_points, st.bound_total,
+                   Bs, Ns, self.quant, L.ptr(st.coords), L.ptr(st.feats), L.ptr(st.pt_off), L.ptr(st.n), L.ptr(st.err), L.stream())
         mb = {"coordinates": st.coords, "features": st.feats, "labels": st.labels, "num_clouds": Bs + st.B, "cloud_group": st.cloud_group,
-              "group_cloud_off": st.gco, "n_dev": st.n, "pt_off": st.pt_off, "gmin_floor": st.gmin_floor, "max_per": st.max_per}
+              "group_cloud_off": st.gco, "n_dev": st.n, "pt_off": st.pt_off, "gmin_floor": st.gmin_floor, "max_per": st.max_per, "flags": flags}
         with L.ws_scope(self._scope + ("p%d" % parity if self.defer else "")):
             out = yield from self._compute_gen(mb, True, stash)
         if self.defer:

@@ -206,8 +206,10 @@ class CloudCoordinateManager(CoordinateManager):
 
     def __init__(self, coords: torch.Tensor, pt_off: torch.Tensor, num_clouds: int, max_points: int, dense_extent=None,
                  cloud_group: Optional[torch.Tensor] = None, num_groups: int = 1, group_cloud_off: Optional[torch.Tensor] = None,
-                 out: Optional[dict] = None, gmin_floor: Optional[torch.Tensor] = None):
-        """``gmin_floor`` (optional, int32 [num_groups, 3]): the minimum stride-4 corner of the clouds of every group that are NOT in this
+                 out: Optional[dict] = None, gmin_floor: Optional[torch.Tensor] = None, flags: Optional[torch.Tensor] = None):
+        """``flags`` (optional, int32 [MAX_LEVELS + 1]): caller-owned count / error words that the caller has ALREADY cleared on this
+        stream (dd3d_assemble_batch does it on the way): no fill launch here.
+        ``gmin_floor`` (optional, int32 [num_groups, 3]): the minimum stride-4 corner of the clouds of every group that are NOT in this
         batch (0x7F7F7F7F = none): dense() then places by the minimum over the whole group, as if all its clouds were here.
         ``out`` (optional): caller-owned buffers for the outputs that outlive the step in the deferred-loss mode of the fused step --
         ``nbr1`` / ``nbr2`` int32 [27, >= N] and ``gro`` int32 [3, num_groups + 1]; their leading dimension is the table stride."""
@@ -221,7 +223,10 @@ class CloudCoordinateManager(CoordinateManager):
         dev = self.device = coords.device
         self.N = int(coords.shape[0])
         self.coords, self._B, self.n_dev = coords, int(num_clouds), pt_off[num_clouds:]
-        flags = torch.zeros(self.MAX_LEVELS + 1, dtype=_I32, device=dev)   # one fill: row counts + the error word
+        if flags is None:
+            flags = torch.zeros(self.MAX_LEVELS + 1, dtype=_I32, device=dev)   # one fill: row counts + the error word
+        elif flags.dtype != _I32 or flags.numel() != self.MAX_LEVELS + 1 or flags.device != dev:
+            raise ValueError("flags must be int32 [MAX_LEVELS + 1] on the coordinates' device")
         self.counts, self.err = flags[:self.MAX_LEVELS], flags[self.MAX_LEVELS:]
         self.levels, self.kmaps, self._synced = {}, {}, False
         B, bound = self._B, max(self.N, 1)

@@ -84,6 +84,15 @@ int dd3d_dense_sites(const int32_t* C, const int32_t* m_dev, int64_t bound, cons
  * mnist_distill.py:200-208, utils/Mnist2D.py:50-59, utils/MinkowskiCollate.py:4-15 */
 int dd3d_gather_clouds(const float* pool_xyz, const int32_t* pool_off, int n_pool, const int32_t* ids, int B, int cap, int64_t bound, int cloud_base,
                        int64_t point_base, float quant /* coords = p / quant (create_input_batch's quantization_size), feats = p */, float* coords, float* feats, int32_t* pt_off, int32_t* n_dev, int32_t* err_dev, void* stream);
+/* dd3d_syn_head + dd3d_gather_clouds in ONE launch (what a captured step runs first): the gathering workgroups sum the point counts of
+ * the clouds before them themselves (no one-workgroup offsets kernel), and `zero_words` ints at `zero` (nullable) are cleared on the way
+ * (the map builder's per-step count / error words).  B >= 1.  Same outputs as the two calls, bit for bit.
+ * replaces: get_images + Mnist2Dreal + minkowski_collate_fn for the real batch, clamp + get_syn_tensor + Mnist2Dsyn for the synthetic
+ * one, mnist_distill.py:200-208,333-343, utils/Mnist2D.py:60-92 */
+int dd3d_assemble_batch(float* xyz, int64_t n_syn_clouds, int npts, const int32_t* dest_cloud, int do_clamp, float lo, float hi, int zero_first,
+                        float quant, const float* pool_xyz, const int32_t* pool_off, int n_pool, const int32_t* ids, int B, int cap, int64_t bound,
+                        int cloud_base, int64_t point_base, float* coords, float* feats, int32_t* pt_off, int32_t* n_dev, int32_t* err_dev,
+                        int32_t* zero, int zero_words, void* stream);
 
 /* The whole coordinate pyramid of MEConvExp.forward in three launches, for batches whose clouds have at most
  * dd3d_cloud_maps_max_points() points each: one workgroup per cloud builds the voxel hashes of tensor strides 1, 2, 4 in LDS

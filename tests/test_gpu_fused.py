@@ -152,6 +152,55 @@ def test_gather_clouds_equals_collate():
         assert int(err.item()) == 4
 
 
+def test_assemble_batch_equals_syn_head_plus_gather_clouds():
+    """dd3d_assemble_batch (clamp + synthetic head + real-batch gather with the offsets computed by the gathering workgroups + cleared flag
+    words, ONE launch) against dd3d_syn_head followed by dd3d_gather_clouds: every output bit for bit -- with a subset of owned synthetic
+    clouds, more real clouds than one offsets pass of 128 lanes, a point cap, a bound that is too small and an id outside the pool."""
+    from dd3d_amd import _lib as L
+    from dd3d_amd.utils.Mnist2D import batch_from_images
+    imgs = stroke_digits(60, seed=5).to(DEV)
+    npts, n_syn, own = 50, 7, [1, 2, 5]                      # 7 synthetic clouds, 3 of them owned by this process
+    pool = batch_from_images(imgs, torch.zeros(60, dtype=torch.long, device=DEV), 250)
+    cnt = torch.bincount(pool["coordinates"][:, 0].long(), minlength=60)
+    off = torch.cat([torch.zeros(1, dtype=torch.long, device=DEV), torch.cumsum(cnt, 0)]).to(torch.int32)
+    xyz = pool["features"].contiguous()
+    g = torch.Generator().manual_seed(3)
+    dest = torch.full((n_syn,), -1, dtype=torch.int32)
+    dest[own] = torch.arange(len(own), dtype=torch.int32)
+    dest = dest.to(DEV)
+    Bs, Ns = len(own), len(own) * npts
+    for (B, cap, bound, bad, flagged) in ((300, 40, Ns + 300 * 40, False, False), (6, 250, Ns + 64, False, True), (9, 30, Ns + 9 * 30, True, True)):
+        ids = torch.randint(0, 60, (B,), generator=g).to(torch.int32)
+        if bad:
+            ids[4], ids[7] = 60, -1
+        ids = ids.to(DEV)
+        syn0 = (torch.rand(n_syn, npts, 3, generator=g) * 40 - 6).to(DEV)   # some points outside the clamp range
+        outs = []
+        for one in (False, True):
+            syn = syn0.clone()
+            coords, feats = torch.full((bound, 4), -1.0, device=DEV), torch.full((bound, 3), -1.0, device=DEV)
+            pt_off = torch.full((Bs + B + 1,), -7, dtype=torch.int32, device=DEV)
+            n, err = torch.zeros(1, dtype=torch.int32, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV)
+            flags = torch.full((9,), 5, dtype=torch.int32, device=DEV)
+            if one:
+                L.call("dd3d_assemble_batch", L.ptr(syn), n_syn, npts, L.ptr(dest), 1, 0.0, 27.0, 1, 0.5, L.ptr(xyz), L.ptr(off), 60, L.ptr(ids), B, cap,
+                       bound, Bs, Ns, L.ptr(coords), L.ptr(feats), L.ptr(pt_off), L.ptr(n), L.ptr(err), L.ptr(flags), 9, L.stream())
+                assert flags.tolist() == [0] * 9
+            else:
+                L.call("dd3d_syn_head", L.ptr(syn), n_syn, npts, L.ptr(dest), 1, 0.0, 27.0, 1, 0.5, L.ptr(coords), L.ptr(feats), L.stream())
+                L.call("dd3d_gather_clouds", L.ptr(xyz), L.ptr(off), 60, L.ptr(ids), B, cap, bound, Bs, Ns, 0.5, L.ptr(coords), L.ptr(feats), L.ptr(pt_off),
+                       L.ptr(n), L.ptr(err), L.stream())
+            torch.cuda.synchronize()
+            outs.append((syn, coords, feats, pt_off, n, err))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+        assert int(outs[1][5].item()) == (4 if flagged else 0)   # a bound that is too small / an id outside the pool
+        assert float(outs[1][0].min()) >= 0.0 and float(outs[1][0].max()) <= 27.0 and float(outs[1][0][:, :, 0].abs().max()) == 0.0
+    # B = 0 is the two-call path's case
+    assert L.lib.dd3d_assemble_batch(L.ptr(syn), n_syn, npts, L.ptr(dest), 1, 0.0, 27.0, 1, 0.5, L.ptr(xyz), L.ptr(off), 60, L.ptr(ids), 0, cap, bound, Bs, Ns,
+                                     L.ptr(coords), L.ptr(feats), L.ptr(pt_off), L.ptr(n), L.ptr(err), None, 0, L.stream()) == -1
+
+
 @pytest.mark.parametrize("classes", [None, [1, 3]])
 @pytest.mark.parametrize("metric", ["modmse", "ours"])
 def test_graph_replay_is_bitwise_the_eager_step(metric, classes):
