@@ -46,6 +46,7 @@ _SIGS = {
     "dd3d_cloud_maps_max_points": (I32, []),
     "dd3d_cloud_maps_ws_bytes": (I64, [I32]),
     "dd3d_cloud_maps": (I32, [P, P, I32, I32, I64, P, I32, I32, I32, I32] + [P] * 17 + [I64, P, P, P, P, P, P, P, P, I64, P]),
+    "dd3d_cloud_maps_f0": (I32, [P, P, I32, I32, I64, P, I32, I32, I32, I32] + [P] * 17 + [I64, P, P, P, P, P, P, P, P, I64, P, P, P]),
     "dd3d_conv_fwd": (I32, [P, I64, I32, P, I32, P, I64, I32, I64, P, I32, P, P]),
     "dd3d_syn_head": (I32, [P, I64, I32, P, I32, F32, F32, I32, F32, P, P, P]),
     "dd3d_sgd_scatter": (I32, [P, P, P, P, I64, I32, F32, F32, P, P]),

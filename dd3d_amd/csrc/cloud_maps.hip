@@ -396,6 +396,8 @@ struct CloudOut {
     int *kid2, *kid4;              // [8][ld] k=2 pooling maps 1->2 and 2->4
     int *site, *vox_at;            // dense placement of stride 4: [bound], [S][B] (nullable pair)
     const int* gmin;               // [G][3]
+    const float* feats;            // [N][3] point features and F0 [bound][3] = their mean per stride-1 voxel (nullable pair)
+    float* F0;
     int64_t ld;
     int E0, E1, E2;
 };
@@ -558,6 +560,15 @@ __global__ __launch_bounds__(CT) void k_cloud_emit(const float4* __restrict__ co
             lpts[j + 1] = x;
         }
         for (int i = a; i < e; ++i) o.vox_pts[p0 + i] = p0 + lpts[i];
+        if (o.F0) {  // TensorField.sparse() averages the features of a voxel's points: k_voxel_mean_fwd's sum, in its order (C = 3)
+            float f[3] = {0.f, 0.f, 0.f};
+            for (int i = a; i < e; ++i) {
+                const float* src = o.feats + (int64_t)(p0 + lpts[i]) * 3;
+                f[0] += src[0]; f[1] += src[1]; f[2] += src[2];
+            }
+            float* dst = o.F0 + (int64_t)(r1 + v) * 3;
+            dst[0] = f[0] / (float)(e - a); dst[1] = f[1] / (float)(e - a); dst[2] = f[2] / (float)(e - a);
+        }
     }
     // stride 2 and 4: coordinates, parents, first rows
     for (int u = tid; u < c.m2; u += CT) {
@@ -652,12 +663,13 @@ DD3D_API int dd3d_cloud_maps_max_points(void) { return 1024; }
 DD3D_API int64_t dd3d_cloud_maps_ws_bytes(int B) { return align_up64((int64_t)(B > 0 ? B : 1) * 6 * 4, 256); }  // counts and minimum corners, [3][B] each
 
 // See include/dd3d.h.  All outputs are sized by `bound` (>= number of points); rows beyond the counts are not written.
-DD3D_API int dd3d_cloud_maps(const float* coords, const int32_t* pt_off, int B, int max_points, int64_t bound, const int32_t* cloud_group, int G,
-                             int E0, int E1, int E2, int32_t* counts /*[3]*/, int32_t* seg /*[3][B+1]*/, int32_t* C1, int32_t* C2, int32_t* C4,
-                             int32_t* inv1, int32_t* uidx1, int32_t* vox_off, int32_t* vox_pts, int32_t* par2, int32_t* uidx2, int32_t* par4,
-                             int32_t* uidx4, int32_t* nbr1, int32_t* nbr2, int32_t* kid2, int32_t* kid4, int64_t ld, int32_t* gmin, int32_t* site,
-                             int32_t* vox_at, const int32_t* group_cloud_off, int32_t* group_row_off /*[3][G+1]*/, const int32_t* gmin_floor /*[G][3] or null*/,
-                             int32_t* err_dev, void* ws, int64_t ws_bytes, void* stream) {
+static int cloud_maps_impl(const float* coords, const int32_t* pt_off, int B, int max_points, int64_t bound, const int32_t* cloud_group, int G,
+                           int E0, int E1, int E2, int32_t* counts /*[3]*/, int32_t* seg /*[3][B+1]*/, int32_t* C1, int32_t* C2, int32_t* C4,
+                           int32_t* inv1, int32_t* uidx1, int32_t* vox_off, int32_t* vox_pts, int32_t* par2, int32_t* uidx2, int32_t* par4,
+                           int32_t* uidx4, int32_t* nbr1, int32_t* nbr2, int32_t* kid2, int32_t* kid4, int64_t ld, int32_t* gmin, int32_t* site,
+                           int32_t* vox_at, const int32_t* group_cloud_off, int32_t* group_row_off /*[3][G+1]*/, const int32_t* gmin_floor /*[G][3] or null*/,
+                           int32_t* err_dev, void* ws, int64_t ws_bytes, void* stream, const float* feats, float* F0) {
+    if ((feats == nullptr) != (F0 == nullptr)) return DD3D_EARG;
     if (B < 0 || max_points <= 0 || max_points > dd3d_cloud_maps_max_points() || bound < 0 || ld < bound || G <= 0 || !counts || !seg || !err_dev)
         return DD3D_EARG;
     if (bound >= (1ll << 31) / 32) return DD3D_ESIZE;
@@ -689,9 +701,35 @@ DD3D_API int dd3d_cloud_maps(const float* coords, const int32_t* pt_off, int B, 
     o.par2 = par2; o.uidx2 = uidx2; o.par4 = par4; o.uidx4 = uidx4;
     o.nbr1 = nbr1; o.nbr2 = nbr2; o.kid2 = kid2; o.kid4 = kid4;
     o.site = site; o.vox_at = vox_at; o.gmin = gmin;
+    o.feats = feats; o.F0 = F0;
     o.ld = ld; o.E0 = E0; o.E1 = E1; o.E2 = E2;
     int* cnt = (int*)ws;
     if (max_points <= 256)
         return launch_cloud_maps<256>((const float4*)coords, pt_off, B, cloud_group, cnt, seg, counts, o, dense ? gmin : nullptr, err_dev, group_cloud_off, G, group_row_off, gmin_floor, st);
     return launch_cloud_maps<1024>((const float4*)coords, pt_off, B, cloud_group, cnt, seg, counts, o, dense ? gmin : nullptr, err_dev, group_cloud_off, G, group_row_off, gmin_floor, st);
+}
+
+DD3D_API int dd3d_cloud_maps(const float* coords, const int32_t* pt_off, int B, int max_points, int64_t bound, const int32_t* cloud_group, int G,
+                             int E0, int E1, int E2, int32_t* counts /*[3]*/, int32_t* seg /*[3][B+1]*/, int32_t* C1, int32_t* C2, int32_t* C4,
+                             int32_t* inv1, int32_t* uidx1, int32_t* vox_off, int32_t* vox_pts, int32_t* par2, int32_t* uidx2, int32_t* par4,
+                             int32_t* uidx4, int32_t* nbr1, int32_t* nbr2, int32_t* kid2, int32_t* kid4, int64_t ld, int32_t* gmin, int32_t* site,
+                             int32_t* vox_at, const int32_t* group_cloud_off, int32_t* group_row_off /*[3][G+1]*/, const int32_t* gmin_floor /*[G][3] or null*/,
+                             int32_t* err_dev, void* ws, int64_t ws_bytes, void* stream) {
+    return cloud_maps_impl(coords, pt_off, B, max_points, bound, cloud_group, G, E0, E1, E2, counts, seg, C1, C2, C4, inv1, uidx1, vox_off, vox_pts, par2, uidx2,
+                           par4, uidx4, nbr1, nbr2, kid2, kid4, ld, gmin, site, vox_at, group_cloud_off, group_row_off, gmin_floor, err_dev, ws, ws_bytes,
+                           stream, nullptr, nullptr);
+}
+
+// dd3d_cloud_maps + dd3d_voxel_mean_fwd for 3-channel point features in the same two launches: F0[bound][3] = mean of feats3[N][3] over the
+// points of every stride-1 voxel (the sum in ascending point order, as dd3d_voxel_mean_fwd: same bits).  Same arguments otherwise.
+DD3D_API int dd3d_cloud_maps_f0(const float* coords, const int32_t* pt_off, int B, int max_points, int64_t bound, const int32_t* cloud_group, int G,
+                                int E0, int E1, int E2, int32_t* counts /*[3]*/, int32_t* seg /*[3][B+1]*/, int32_t* C1, int32_t* C2, int32_t* C4,
+                                int32_t* inv1, int32_t* uidx1, int32_t* vox_off, int32_t* vox_pts, int32_t* par2, int32_t* uidx2, int32_t* par4,
+                                int32_t* uidx4, int32_t* nbr1, int32_t* nbr2, int32_t* kid2, int32_t* kid4, int64_t ld, int32_t* gmin, int32_t* site,
+                                int32_t* vox_at, const int32_t* group_cloud_off, int32_t* group_row_off /*[3][G+1]*/, const int32_t* gmin_floor /*[G][3] or null*/,
+                                int32_t* err_dev, void* ws, int64_t ws_bytes, void* stream, const float* feats3, float* F0) {
+    if (!feats3 || !F0) return DD3D_EARG;
+    return cloud_maps_impl(coords, pt_off, B, max_points, bound, cloud_group, G, E0, E1, E2, counts, seg, C1, C2, C4, inv1, uidx1, vox_off, vox_pts, par2, uidx2,
+                           par4, uidx4, nbr1, nbr2, kid2, kid4, ld, gmin, site, vox_at, group_cloud_off, group_row_off, gmin_floor, err_dev, ws, ws_bytes,
+                           stream, feats3, F0);
 }

@@ -92,7 +92,7 @@ class _Pass:
     pass is the same kernels called on the first ``B_syn`` clouds with the prefix's row counts (``seg_off[B_syn]``, on the device)."""
 
     def __init__(self, net, coords, B, G, cloud_group, group_cloud_off, B_syn, N_syn, side, n_dev=None, static=False, pt_off=None, max_points=0,
-                 extent=None, side2=None, stash=None, Gs=None, dl_scale=None, gmin_floor=None, max_per_group=0, flags=None):
+                 extent=None, side2=None, stash=None, Gs=None, dl_scale=None, gmin_floor=None, max_per_group=0, flags=None, feats3=None):
         """Phase 1 (no host sync): every coordinate map, enqueued on the current stream.
         ``static``: never read a size back -- every launch covers its bound and takes the true row count from the device
         (``n_dev`` = number of valid rows of ``coords``), so the pass can be captured into a HIP graph."""
@@ -111,7 +111,7 @@ class _Pass:
             # clouds small enough for LDS: the whole pyramid (+ dense placement) in three launches
             cm = CloudCoordinateManager(coords, pt_off, B, max_points, extent, cloud_group, G, group_cloud_off,
                                         out=None if stash is None else {k: stash[k] for k in ("nbr1", "nbr2", "gro")}, gmin_floor=gmin_floor,
-                                        flags=flags)
+                                        flags=flags, feats3=feats3, F0_out=None if stash is None else stash["F0"])
         else:
             if stash is not None or gmin_floor is not None:
                 raise ValueError("the deferred-loss mode and split real batches need the cloud-local map builder (clouds of at most 1024 points)")
@@ -175,8 +175,11 @@ class _Pass:
 
         # ---------------- forward ----------------
         feats = feats.detach().contiguous()
-        F0 = self.F0 = stash["F0"][:M0] if stash is not None else _empty((M0, 3), dev)
-        L.call("dd3d_voxel_mean_fwd", L.ptr(feats), self.N, 3, L.ptr(cm.vox_off), L.ptr(cm.vox_pts), M0, c0, L.ptr(F0), st)
+        if getattr(cm, "F0", None) is not None:   # the map builder averaged the features per voxel on its way (dd3d_cloud_maps_f0)
+            F0 = self.F0 = cm.F0[:M0]
+        else:
+            F0 = self.F0 = stash["F0"][:M0] if stash is not None else _empty((M0, 3), dev)
+            L.call("dd3d_voxel_mean_fwd", L.ptr(feats), self.N, 3, L.ptr(cm.vox_off), L.ptr(cm.vox_pts), M0, c0, L.ptr(F0), st)
         Y0 = _empty((M0, 128), dev)
         L.call("dd3d_conv_fwd", L.ptr(F0), M0, 3, L.ptr(W0), 128, L.ptr(k0), ld0, 27, M0, c0, 0, L.ptr(Y0), st)
         # The normalised rows are never written: the level keeps Y, the per-cloud mean and inv_std, and every later pass normalises a row
@@ -887,7 +890,8 @@ class FusedDistiller:
         p = _Pass(net, mb["coordinates"], int(mb["num_clouds"]), G + self.Gr, mb["cloud_group"], mb["group_cloud_off"], G * ipc, G * ipc * npts,
                   self.stream_side, mb.get("n_dev"), static, mb.get("pt_off"), npts, extent, self.stream_side2, stash, Gs=G,
                   dl_scale=self.dl_scale, gmin_floor=mb.get("gmin_floor"), max_per_group=max(ipc, int(mb.get("max_per") or mb["num_clouds"])),
-                  flags=mb.get("flags"))
+                  flags=mb.get("flags"),
+                  feats3=mb["features"].detach().contiguous() if os.environ.get("DD3D_MAPS_F0", "1") != "0" and mb["features"].shape[1] == 3 else None)
         p.run(mb["features"], mb["labels"], defer=stash is not None)
         gw_syn, gw_real = [None if t is None else t[:G] for t in p.gw], [None if t is None else t[G:] for t in p.gw]
         # Only these entries of gw_syn depend on the synthetic points: IN weights, classifier weight and bias.  For the

@@ -206,8 +206,12 @@ class CloudCoordinateManager(CoordinateManager):
 
     def __init__(self, coords: torch.Tensor, pt_off: torch.Tensor, num_clouds: int, max_points: int, dense_extent=None,
                  cloud_group: Optional[torch.Tensor] = None, num_groups: int = 1, group_cloud_off: Optional[torch.Tensor] = None,
-                 out: Optional[dict] = None, gmin_floor: Optional[torch.Tensor] = None, flags: Optional[torch.Tensor] = None):
-        """``flags`` (optional, int32 [MAX_LEVELS + 1]): caller-owned count / error words that the caller has ALREADY cleared on this
+                 out: Optional[dict] = None, gmin_floor: Optional[torch.Tensor] = None, flags: Optional[torch.Tensor] = None,
+                 feats3: Optional[torch.Tensor] = None, F0_out: Optional[torch.Tensor] = None):
+        """``feats3`` (optional, float32 [N, 3]): the points' features; the builder then also averages them per stride-1 voxel
+        (``self.F0`` [N, 3], rows beyond the voxel count unwritten; ``F0_out``: a caller-owned buffer for it) -- dd3d_voxel_mean_fwd's bits
+        without its launch.
+        ``flags`` (optional, int32 [MAX_LEVELS + 1]): caller-owned count / error words that the caller has ALREADY cleared on this
         stream (dd3d_assemble_batch does it on the way): no fill launch here.
         ``gmin_floor`` (optional, int32 [num_groups, 3]): the minimum stride-4 corner of the clouds of every group that are NOT in this
         batch (0x7F7F7F7F = none): dense() then places by the minimum over the whole group, as if all its clouds were here.
@@ -249,11 +253,18 @@ class CloudCoordinateManager(CoordinateManager):
             self.dense_tables = (E, cloud_group, gmin, site, vox_at)
         self.group_row_off = (out["gro"] if "gro" in out else i32(3, num_groups + 1)) if group_cloud_off is not None else None   # rows of every group at strides 1, 2, 4
         ws = L.workspace(int(L.lib.dd3d_cloud_maps_ws_bytes(B)), dev)
-        L.call("dd3d_cloud_maps", L.ptr(coords), L.ptr(pt_off), B, int(max_points), self.N, L.ptr(cloud_group), int(num_groups), E[0], E[1], E[2],
+        self.F0 = None
+        extra = ()
+        if feats3 is not None:
+            if feats3.dtype != torch.float32 or tuple(feats3.shape) != (self.N, 3) or not feats3.is_contiguous() or feats3.device != dev:
+                raise ValueError("feats3 must be contiguous float32 [N, 3] on the coordinates' device")
+            self.F0 = F0_out[:bound] if F0_out is not None else torch.empty((bound, 3), dtype=torch.float32, device=dev)
+            extra = (L.ptr(feats3), L.ptr(self.F0))
+        L.call("dd3d_cloud_maps_f0" if extra else "dd3d_cloud_maps", L.ptr(coords), L.ptr(pt_off), B, int(max_points), self.N, L.ptr(cloud_group), int(num_groups), E[0], E[1], E[2],
                L.ptr(self.counts), L.ptr(seg), L.ptr(C[0]), L.ptr(C[1]), L.ptr(C[2]), L.ptr(inv1), L.ptr(uidx1), L.ptr(self.vox_off),
                L.ptr(self.vox_pts), L.ptr(par2), L.ptr(uidx2), L.ptr(par4), L.ptr(uidx4), L.ptr(nbr1), L.ptr(nbr2), L.ptr(kid2), L.ptr(kid4), bound,
                L.ptr(gmin), L.ptr(site), L.ptr(vox_at), L.ptr(group_cloud_off), L.ptr(self.group_row_off), L.ptr(gmin_floor), L.ptr(self.err), L.ptr(ws),
-               ws.numel(), L.stream())
+               ws.numel(), L.stream(), *extra)
         for slot, (stride, inv, uidx) in enumerate(((1, inv1, uidx1), (2, par2, uidx2), (4, par4, uidx4))):
             lv = _Level()
             lv.stride, lv.bound, lv.slot, lv.cap, lv.table = stride, self.N, slot, 0, None

@@ -118,6 +118,14 @@ int dd3d_cloud_maps(const float* coords, const int32_t* pt_off, int B, int max_p
                     int32_t* vox_off, int32_t* vox_pts, int32_t* par2, int32_t* uidx2, int32_t* par4, int32_t* uidx4, int32_t* nbr1, int32_t* nbr2,
                     int32_t* kid2, int32_t* kid4, int64_t ld, int32_t* gmin, int32_t* site, int32_t* vox_at, const int32_t* group_cloud_off,
                     int32_t* group_row_off, const int32_t* gmin_floor, int32_t* err_dev, void* ws, int64_t ws_bytes, void* stream);
+/* dd3d_cloud_maps + dd3d_voxel_mean_fwd for 3-channel point features in the same launches: F0[bound][3] = mean of feats3[N][3] over the
+ * points of every stride-1 voxel (summed in ascending point order: the bits of dd3d_voxel_mean_fwd).  Same arguments otherwise.
+ * replaces: x.sparse() including its feature average, models/MEConv.py:247 */
+int dd3d_cloud_maps_f0(const float* coords, const int32_t* pt_off, int B, int max_points, int64_t bound, const int32_t* cloud_group, int G, int E0,
+                    int E1, int E2, int32_t* counts, int32_t* seg, int32_t* C1, int32_t* C2, int32_t* C4, int32_t* inv1, int32_t* uidx1,
+                    int32_t* vox_off, int32_t* vox_pts, int32_t* par2, int32_t* uidx2, int32_t* par4, int32_t* uidx4, int32_t* nbr1, int32_t* nbr2,
+                    int32_t* kid2, int32_t* kid4, int64_t ld, int32_t* gmin, int32_t* site, int32_t* vox_at, const int32_t* group_cloud_off,
+                    int32_t* group_row_off, const int32_t* gmin_floor, int32_t* err_dev, void* ws, int64_t ws_bytes, void* stream, const float* feats3, float* F0);
 
 /* ---------------------------------------------------------------------------------------------------------------------
  * (2) sparse convolution, gather-GEMM with atomic-free output (fp32 MFMA for Cin = 128)

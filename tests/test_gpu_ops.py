@@ -469,6 +469,17 @@ def test_cloud_local_maps_equal_generic_maps(case):
         assert torch.equal(cm.kernel_map(si, so, k)[0][:, :Mo], ref.kernel_map(si, so, k)[0][:, :Mo]), (si, so, k)
     assert torch.equal(dcm.gmin, dref.gmin)
     assert torch.equal(dcm.site[:Ms[2]], dref.site[:Ms[2]]) and torch.equal(dcm.vox_at, dref.vox_at)
+    # dd3d_cloud_maps_f0: the same maps plus the per-voxel feature mean of dd3d_voxel_mean_fwd, bit for bit (with group_cloud_off: the scan
+    # inside pass B)
+    from dd3d_amd import _lib as L
+    feats = torch.randn(padded.shape[0], 3, generator=torch.Generator().manual_seed(5)).to(dev())
+    cf = CloudCoordinateManager(padded, pt_off, B, maxp, ext, cg, G, gco, feats3=feats)
+    cf.sync()
+    want = torch.full((Ms[0], 3), 7.0, device=dev())
+    L.call("dd3d_voxel_mean_fwd", L.ptr(feats), N, 3, L.ptr(ref.vox_off), L.ptr(ref.vox_pts), Ms[0], None, L.ptr(want), L.stream())
+    assert torch.equal(cf.F0[:Ms[0]], want)
+    assert torch.equal(cf.kernel_map(2, 2, 3)[0][:, :Ms[1]], ref.kernel_map(2, 2, 3)[0][:, :Ms[1]]) and torch.equal(cf.seg_off(4), ref.seg_off(4))
+    assert torch.equal(cf.group_row_off[:, 1], torch.stack([ref.seg_off(s)[B // 3] for s in (1, 2, 4)]))
 
 
 def test_cloud_local_maps_flag_errors():
