@@ -430,9 +430,21 @@ __global__ __launch_bounds__(128) void k_assemble_batch(float* __restrict__ xyz,
         for (int i = tid; i < zero_words; i += 128) zero[i] = 0;
     // points of the clouds before this one (an index outside the pool: an empty cloud, flagged by the cloud's own workgroup)
     int sum = 0;
-    for (int i = tid; i < b; i += 128) {
-        const int id = ids[i];
-        if (id >= 0 && id < n_pool) sum += min(pool_off[id + 1] - pool_off[id], cap);
+    for (int i0 = tid; i0 < b; i0 += 128 * 8) {  // eight clouds of this lane at a time: their ids, then their 16 offsets, in flight together
+        int id[8], lo8[8], hi8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i = i0 + 128 * q;
+            id[q] = i < b ? ids[i] : -1;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const bool okq = id[q] >= 0 && id[q] < n_pool;
+            lo8[q] = pool_off[okq ? id[q] : 0];
+            hi8[q] = okq ? pool_off[id[q] + 1] : lo8[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sum += min(hi8[q] - lo8[q], cap);
     }
     sum = wave_sum_i(sum);
     if ((tid & 63) == 0) s_w[tid >> 6] = sum;

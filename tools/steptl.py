@@ -2,7 +2,7 @@
 import csv, glob, os, re, sys
 f = max(glob.glob(sys.argv[1] + '/*/*_kernel_trace.csv'), key=os.path.getmtime)
 rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], r["Kernel_Name"]) for r in csv.DictReader(open(f)))
-idx = [i for i, r in enumerate(rows) if 'k_syn_head' in r[3]]
+idx = [i for i, r in enumerate(rows) if 'k_syn_head' in r[3] or 'k_assemble_batch' in r[3]]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 a, b = idx[k], idx[k + 1]
 t0 = rows[a][0]
