@@ -65,6 +65,10 @@ def main():
     ap.add_argument("--real-split", default="off", help="second sharding level (graph / fused path): 'off' = classes only; 'auto' or P = the real batch "
                                                         "of every class of a shard split over P ranks, partial gradients all-reduced in the group "
                                                         "(sharding.split_layout).  With --emulate-shard the exchange is left out (compute share only)")
+    ap.add_argument("--reduce-loss", default="end", choices=["end", "step"],
+                    help="world > 1: when the per-rank matching losses are summed over RCCL.  Nothing in a step needs the global sum (the classes' "
+                         "terms are independent, mnist_distill.py:335-361; the reference only prints it), so it is reduced where it is READ: once, "
+                         "after the last timed step, inside the timed region (end, default) -- or after every step (step)")
     ap.add_argument("--defer-loss", action="store_true", help="graph path: compute each step's loss VALUE next to the following step (measured slower: DESIGN.md section 3)")
     ap.add_argument("--path", default="graph", choices=["graph", "fused", "dropin"],
                     help="graph: class-batched step captured into one HIP graph (default); fused: the same step enqueued eagerly; "
@@ -173,7 +177,8 @@ def main():
             for i, (nbr, M, cnt) in enumerate(d.last["conv1_maps"]):
                 m = M if cnt is None else d.row_counts()[i][1]
                 pairs.append(int((nbr[:, :m] >= 0).sum().item()))
-        return reduce_loss(loss)  # summed matching loss (mnist_distill.py:361,373): 4 bytes over RCCL when world > 1
+        # summed matching loss (mnist_distill.py:361,373): 4 bytes over RCCL when world > 1, per step or where the value is read (--reduce-loss)
+        return reduce_loss(loss) if args.reduce_loss == "step" else loss
 
     for _ in range(max(args.warmup, 2 if args.path == "graph" else 0)):   # graph mode: step 1 sizes the workspaces, step 2 captures
         one_step()
@@ -185,7 +190,11 @@ def main():
     if getattr(d, "defer", False):
         # deferred-loss mode: every replay carried the loss-value work of the step before it; the last step's is completed here, INSIDE the
         # timed region, so the K timed steps contain K times the whole work of a step
-        loss = reduce_loss(d.flush())
+        loss = d.flush()
+        if args.reduce_loss == "step":
+            loss = reduce_loss(loss)
+    if args.reduce_loss == "end":
+        loss = reduce_loss(loss)   # the value is read below: summed over the ranks here, inside the timed region
     sync_all()
     dt = time.perf_counter() - t0
     timer.on = False
@@ -283,6 +292,7 @@ def main():
                                                             f"ipc={args.ipc} x {NUM_POINTS} pts, MEConvExp, dist_opt={args.metric_name}") if args.config != "cfg4" else
                                                            (f"cfg4: ModelNet40-shaped ellipsoid shells, 40 classes x {REAL_PER_CLASS} real clouds x 1024 pts, voxel 0.05, "
                                                             f"ipc={args.ipc}, MEConvExp(num_classes=40, dense_extent=12^3), dist_opt={args.metric_name}"),
+                                               "loss_all_reduce": ("per step" if args.reduce_loss == "step" else "once, after the last timed step (inside the timed region)") if world > 1 else None,
                                                "parallelism": f"class-sharded x{world}" + (f", real batches split x{split_kw['real_part'][1]}" if split_kw else ""),
                                                "path": {"graph": "class-batched step, one HIP graph replay per step", "fused": "class-batched step, eager launches",
                                                         "dropin": "drop-in autograd loop"}[args.path]},
