@@ -65,10 +65,11 @@ def main():
     ap.add_argument("--real-split", default="off", help="second sharding level (graph / fused path): 'off' = classes only; 'auto' or P = the real batch "
                                                         "of every class of a shard split over P ranks, partial gradients all-reduced in the group "
                                                         "(sharding.split_layout).  With --emulate-shard the exchange is left out (compute share only)")
-    ap.add_argument("--reduce-loss", default="end", choices=["end", "step"],
-                    help="world > 1: when the per-rank matching losses are summed over RCCL.  Nothing in a step needs the global sum (the classes' "
-                         "terms are independent, mnist_distill.py:335-361; the reference only prints it), so it is reduced where it is READ: once, "
-                         "after the last timed step, inside the timed region (end, default) -- or after every step (step)")
+    ap.add_argument("--reduce-loss", default="step", choices=["step", "end"],
+                    help="world > 1: when the per-rank matching losses are summed over RCCL.  step (default): after every step -- the reference "
+                         "sums the classes' terms and READS the total every iteration (mnist_distill.py:361,373: loss.item() feeds loss_avg and "
+                         "the least-loss checkpoint), so the per-step 4-byte all-reduce is part of the step; end: once, after the last timed "
+                         "step, inside the timed region (a measurement option: config.loss_all_reduce records which one was timed)")
     ap.add_argument("--defer-loss", action="store_true", help="graph path: compute each step's loss VALUE next to the following step (measured slower: DESIGN.md section 3)")
     ap.add_argument("--path", default="graph", choices=["graph", "fused", "dropin"],
                     help="graph: class-batched step captured into one HIP graph (default); fused: the same step enqueued eagerly; "

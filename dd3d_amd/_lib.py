@@ -154,8 +154,26 @@ class ws_scope:
 
 
 def drop_scope(tag: str):
-    for k in [k for k in _ws_cache if k[2] == tag]:
+    """Forget the workspaces of scope ``tag`` and of its sub-scopes (``tag`` + suffix)."""
+    for k in [k for k in _ws_cache if k[2].startswith(tag)]:
         del _ws_cache[k]
+
+
+_hip = None
+
+
+def hip_last_error() -> str:
+    """Name of the HIP runtime's pending error ("" if none), WITHOUT clearing it (hipPeekAtLastError of the runtime this process already
+    has loaded): what a teardown prints so that a failure names itself."""
+    global _hip
+    try:
+        if _hip is None:
+            _hip = C.CDLL("libamdhip64.so.7")   # by SONAME: the runtime torch and libdd3d_hip.so already share, never a second copy
+            _hip.hipGetErrorName.restype = C.c_char_p
+        rc = int(_hip.hipPeekAtLastError())
+        return "" if rc == 0 else "%s (%d)" % ((_hip.hipGetErrorName(rc) or b"?").decode(), rc)
+    except Exception:
+        return ""
 
 
 def workspace(nbytes: int, device, tag: str = "ws") -> torch.Tensor:

@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256) void k_offset_mask(const int* __restrict__ nbr
 
 __global__ __launch_bounds__(256, 3) void k_conv128_bww(const float* __restrict__ X, const float* __restrict__ dY, const int* __restrict__ nbr, int64_t ld,
                                                      int K, const int* __restrict__ group_row_off, int G, float* __restrict__ slabs,
-                                                     int* __restrict__ slab_valid, const unsigned* __restrict__ active) {
+                                                     int* __restrict__ slab_valid, const unsigned* __restrict__ active, int order) {
     // The (in,out) pairs of offset k inside the chunk are first COMPACTED (stable ballot scan, 1024 rows per window), so the matrix
     // cores only see rows that have a neighbour; the contraction then runs over 32 pairs per step, in the shape of k_conv128_rows:
     // wave w owns input channels [32w, 32w+32) and all 128 output channels (four 32x32 accumulators); its A operand -- X^T of the
@@ -476,9 +476,22 @@ __global__ __launch_bounds__(256, 3) void k_conv128_bww(const float* __restrict_
     // blockIdx.y = index among the offsets present anywhere (k_offset_mask); the grid's x extent is a multiple of 8, so the workgroups
     // of one chunk -- which read the same dY rows and nearly the same X rows -- land on one XCD and share its L2
     unsigned am = *active;
-    if ((int)blockIdx.y >= __popc(am)) return;
-    for (int j = 0; j < (int)blockIdx.y; ++j) am &= am - 1;
-    const int c = blockIdx.x, k = __builtin_ctz(am);
+    int c, kidx;
+    if (order) {
+        // chunk-major dispatch: workgroups are dealt to the 8 XCDs round-robin in linear order, so linear id L -> XCD L & 7, and the
+        // `nact` workgroups that share chunk c (same dY rows, nearly the same X rows) are CONSECUTIVE on one XCD: they run at the same
+        // time and the chunk's operands are fetched into that XCD's L2 once instead of once per offset
+        const int nact = __popc(am), L = blockIdx.x + gridDim.x * blockIdx.y, j = L >> 3;
+        if (nact == 0) return;
+        kidx = j % nact;
+        c = (j / nact) * 8 + (L & 7);
+        if (c >= (int)gridDim.x) return;
+    } else {
+        if ((int)blockIdx.y >= __popc(am)) return;
+        kidx = blockIdx.y, c = blockIdx.x;
+    }
+    for (int j = 0; j < kidx; ++j) am &= am - 1;
+    const int k = __builtin_ctz(am);
     int g, r0, r1;
     const int CH = chunk128(group_row_off[G]);
     if (!resolve_chunk(c, group_row_off, G, CH, &g, &r0, &r1)) return;
@@ -1135,7 +1148,8 @@ DD3D_API int dd3d_conv_bwd_weight(const float* X, int Cin, const float* dY, int 
             {
             DD3D_HIP(hipMemsetAsync(active, 0, 4, st));
             k_offset_mask<<<dim3((unsigned)(ceil_div64(M_out, 256) < 1024 ? ceil_div64(M_out, 256) : 1024)), 256, 0, st>>>(nbr, ld, K, group_row_off, G, active);  // one row per thread up to 262144 rows
-            k_conv128_bww<<<dim3((unsigned)(ceil_div64(slots, 8) * 8), K), 256, 0, st>>>(X, dY, nbr, ld, K, group_row_off, G, slabs, valid, active);
+            static const int order = getenv("DD3D_BWW_ORDER") ? atoi(getenv("DD3D_BWW_ORDER")) : 1;
+            k_conv128_bww<<<dim3((unsigned)(ceil_div64(slots, 8) * 8), K), 256, 0, st>>>(X, dY, nbr, ld, K, group_row_off, G, slabs, valid, active, order);
         }
     }
     if (Cin == 3)

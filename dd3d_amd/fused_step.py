@@ -19,6 +19,8 @@ from __future__ import annotations
 
 import ctypes
 import os
+import warnings
+import weakref
 from typing import List, Optional
 
 import numpy as np
@@ -58,9 +60,6 @@ def conv_kernel_gradient(X, Cin, dY, nbr, ld, M, gro, G, dev, seg=None, B=0, err
     return dW
 
 
-_COUNTERS = {}
-
-
 def _cw_site_major():
     """Layout of the per-class classifier-weight gradients inside the step: [G, J, S, 128] (sites outside the channels; default) or the
     parameter's own [G, J, 128, S] (DD3D_CW_LAYOUT=cs).  With the channels innermost ``k_sl_bwd_w`` writes whole 512-byte rows instead of
@@ -75,11 +74,9 @@ def _cw_strides(J, C, S):
 
 
 def _group_counters(dev, G):
-    """G zero ints for the kernels that elect a group's last workgroup (they leave the counters at zero): one buffer per device, zeroed once."""
-    buf = _COUNTERS.get(dev)
-    if buf is None or buf.numel() < G:   # (the first step of a distiller is never captured)
-        buf = _COUNTERS[dev] = torch.zeros(max(G, 1024), dtype=_I32, device=dev)
-    return buf
+    """G zero ints for the kernels that elect a group's last workgroup (they leave the counters at zero).  One buffer per OWNER (a
+    FusedDistiller keeps its own beside its captured graphs, which hold the address): never shared between distillers, never regrown."""
+    return torch.zeros(max(int(G), 1), dtype=_I32, device=dev)
 
 
 class _Pass:
@@ -92,7 +89,7 @@ class _Pass:
     pass is the same kernels called on the first ``B_syn`` clouds with the prefix's row counts (``seg_off[B_syn]``, on the device)."""
 
     def __init__(self, net, coords, B, G, cloud_group, group_cloud_off, B_syn, N_syn, side, n_dev=None, static=False, pt_off=None, max_points=0,
-                 extent=None, side2=None, stash=None, Gs=None, dl_scale=None, gmin_floor=None, max_per_group=0, flags=None, feats3=None):
+                 extent=None, side2=None, stash=None, Gs=None, dl_scale=None, gmin_floor=None, max_per_group=0, flags=None, feats3=None, counters=None):
         """Phase 1 (no host sync): every coordinate map, enqueued on the current stream.
         ``static``: never read a size back -- every launch covers its bound and takes the true row count from the device
         (``n_dev`` = number of valid rows of ``coords``), so the pass can be captured into a HIP graph."""
@@ -103,6 +100,8 @@ class _Pass:
         # gradient (a rank holding n_part of a class's n clouds contributes sum(CE) / n, not its own mean)
         self.B_syn, self.N_syn, self.Gs, self.dl_scale = B_syn, N_syn, (G // 2 if Gs is None else Gs), dl_scale
         self.max_per_group = max_per_group if max_per_group > 0 else B   # clouds of the largest group (a bound)
+        # election counters of dd3d_classifier_head: the owner's buffer (zero between launches), or a fresh one for a stand-alone pass
+        self.counters = counters if counters is not None and counters.numel() >= G else _group_counters(dev, G)
         self.cloud_group, self.gco = cloud_group, group_cloud_off
         self.static, self.side, self.side2 = static, side, side2 if side2 is not None else side
         # dense() placement over `extent` sites per axis: the network's dense extent, or the (smaller) box the voxels can actually reach
@@ -233,7 +232,7 @@ class _Pass:
         ws = L.workspace(int(L.lib.dd3d_sparse_linear_ws_bytes(dp.M_bound, J)), dev)
         L.call("dd3d_classifier_head", L.ptr(P1), L.ptr(dp.site), L.ptr(dp.C), dp.M_bound, L.ptr(dp.seg_off), B, 128, None, L.ptr(Wsm), sst, J,
                L.ptr(cls_b), L.ptr(labels), L.ptr(group_cloud_off), G, int(self.max_per_group), L.ptr(logits), L.ptr(prob), L.ptr(dl), L.ptr(closs),
-               L.ptr(self.ce), None if self.dl_scale is not None else L.ptr(g_cb), L.ptr(_group_counters(dev, G)), L.ptr(ws), ws.numel(), st)
+               L.ptr(self.ce), None if self.dl_scale is not None else L.ptr(g_cb), L.ptr(self.counters), L.ptr(ws), ws.numel(), st)
         if self.dl_scale is not None:   # every first-order gradient below is linear in dl
             dl[self.B_syn:].mul_(self.dl_scale)
 
@@ -482,7 +481,7 @@ class _SgdState:
     path carry the reference's ``optimizer_state_dict`` (mnist_distill.py:394) and load into a torch SGD in either code base."""
 
     def __init__(self, owner):
-        self._o = owner
+        self._o = weakref.proxy(owner)   # no reference cycle: a dropped distiller is freed by its reference count, where it is dropped
 
     def state_dict(self):
         o = self._o
@@ -600,6 +599,8 @@ class FusedDistiller:
         self._graph = self._static = None
         self._graph_stamp, self._needs_eager, self._last_loss = None, False, None
         self._scope = "graph%x" % id(self)
+        self._counters = _group_counters(dev, G + self.Gr)   # this distiller's own (its graphs keep the address)
+        self._closed = False
 
     def _param_stamp(self):
         """(address, version) of every network parameter: what the captured graph and its cached weight layouts were built from."""
@@ -653,9 +654,38 @@ class FusedDistiller:
             out.append(max(1, min(E[a], hi // 4 - lo // 4 + 1)))
         return tuple(out)
 
+    def close(self):
+        """Release everything the device may still be using, in a safe order: wait for the distiller's streams (a replay or an eager step
+        may still be running on up to four of them), THEN drop the captured graphs and every buffer they hold addresses of, and last the
+        workspace scopes.  Idempotent; called by ``__del__``.  Any HIP error pending before or raised by the teardown is reported as a
+        warning that names it, so a failing teardown says what failed instead of aborting the process from a destructor."""
+        if getattr(self, "_closed", True):   # (also: a constructor that raised before the streams existed)
+            return
+        self._closed = True
+        before = L.hip_last_error()
+        try:
+            for s in (self.stream_side, self.stream_side2, self.stream_data):
+                s.synchronize()
+            torch.cuda.synchronize(self.device)
+        except Exception as e:   # never raise out of a destructor
+            warnings.warn("FusedDistiller.close(): synchronisation failed: %r" % (e,))
+        self._graph, self._graphs, self._pending, self._stash, self._prefetched = None, [None, None], None, None, None
+        self.last = {}
+        self._static = None
+        L.drop_scope(self._scope)
+        after = L.hip_last_error()
+        if before or after:
+            warnings.warn("FusedDistiller.close(): HIP error pending before teardown: %s; after: %s" % (before or "none", after or "none"))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
     def __del__(self):
         try:
-            L.drop_scope(self._scope)
+            self.close()
         except Exception:
             pass
 
@@ -890,7 +920,7 @@ class FusedDistiller:
         p = _Pass(net, mb["coordinates"], int(mb["num_clouds"]), G + self.Gr, mb["cloud_group"], mb["group_cloud_off"], G * ipc, G * ipc * npts,
                   self.stream_side, mb.get("n_dev"), static, mb.get("pt_off"), npts, extent, self.stream_side2, stash, Gs=G,
                   dl_scale=self.dl_scale, gmin_floor=mb.get("gmin_floor"), max_per_group=max(ipc, int(mb.get("max_per") or mb["num_clouds"])),
-                  flags=mb.get("flags"),
+                  flags=mb.get("flags"), counters=self._counters,
                   feats3=mb["features"].detach().contiguous() if os.environ.get("DD3D_MAPS_F0", "1") != "0" and mb["features"].shape[1] == 3 else None)
         p.run(mb["features"], mb["labels"], defer=stash is not None)
         gw_syn, gw_real = [None if t is None else t[:G] for t in p.gw], [None if t is None else t[G:] for t in p.gw]
@@ -1026,6 +1056,8 @@ class FusedDistiller:
     def outer_step(self, real_batch=None, apply_update=True, force_eager=False):
         """One matching step (mnist_distill.py:309-369 without evaluation/logging).  Returns the summed matching loss (0-d device
         tensor; in graph mode it is a fixed buffer overwritten by the next step)."""
+        if self._closed:
+            raise RuntimeError("this FusedDistiller was closed")
         self._apply_update = apply_update
         if self.use_graph and real_batch is None and apply_update:
             if self._static is None:
@@ -1035,14 +1067,7 @@ class FusedDistiller:
                 self.invalidate()   # a weight changed (load_state_dict, optimizer step): the captured graph reads stale cached layouts
             parity = self.steps_done % 2 if self.defer else 0
             if force_eager or self.steps_done == 0 or self._needs_eager:
-                # the first step runs eagerly: it sizes the workspaces and builds the cached weight layouts the graph will reuse.
-                # An earlier distiller that was dropped (captured graphs, side-stream tensors, workspace scope: it sits in reference
-                # cycles) is collected HERE, before anything is enqueued, not wherever the cyclic collector happens to run inside the
-                # multi-stream step (a full-suite run aborted once in such a collection pass); torch.cuda.graph() does the same
-                # before every capture.
-                if self.steps_done == 0:
-                    import gc
-                    gc.collect()
+                # the first step runs eagerly: it sizes the workspaces and builds the cached weight layouts the graph will reuse
                 loss = self._static_body(parity)
                 self._needs_eager = False
             else:

@@ -22,16 +22,8 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
-@pytest.fixture(autouse=True)
-def _quiescent_teardown():
-    """GPU tests leave distillers behind (captured HIP graphs, side-stream tensors, workspace scopes) that sit in reference cycles.
-    Collect them HERE, with the device idle, instead of wherever the cyclic collector happens to run -- e.g. inside the next test's
-    first multi-stream step (a full-suite run once aborted in a collection pass at exactly such a point, without any GPU fault
-    reported)."""
-    yield
-    import torch
-    if torch.cuda.is_available():
-        import gc
-        torch.cuda.synchronize()
-        gc.collect()
-        torch.cuda.synchronize()
+def pytest_sessionstart(session):
+    # a fatal signal (SIGABRT from the runtime, a segfault inside a HIP call) leaves the Python stack of every thread on the real stderr
+    import faulthandler
+    if not faulthandler.is_enabled():
+        faulthandler.enable(all_threads=True)

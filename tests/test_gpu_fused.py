@@ -471,6 +471,45 @@ def test_deferred_loss_mode_is_the_same_step_one_step_later(metric):
     assert all(g is not None for g in fd._graphs)
 
 
+def test_dropped_graph_distiller_is_torn_down_where_it_is_dropped():
+    """Teardown of a distiller with captured graphs: it sits in no reference cycle, so dropping the last reference frees it THERE (not in
+    some later pass of the cyclic collector), and close() -- which __del__ calls -- waits for the distiller's streams before the graphs
+    and their workspaces go.  A collection pass in the middle of the next distiller's steps must then find nothing of it; close() is
+    idempotent and a closed distiller refuses to step."""
+    import gc
+    import weakref
+    from dd3d_amd import _lib as L
+    from dd3d_amd.fused_step import FusedDistiller
+    from dd3d_amd.synthetic import mnist3d_like
+    images, _, idx = mnist3d_like(3, 30, seed=5)
+    kw = dict(ipc=2, num_classes=3, batch_size=16, device=DEV, seed=4, image_syn=init_synthetic(3, 2, 250, seed=2))
+    f = FusedDistiller(images, idx, _net(), graph=True, **kw)
+    want = [f.outer_step().item() for _ in range(3)]
+    assert f._graph is not None
+    scope, ref = f._scope, weakref.ref(f)
+    assert any(k[2].startswith(scope) for k in L._ws_cache)
+    gc.disable()
+    try:
+        del f                                   # the replay may still be running: close() synchronises first
+        assert ref() is None, "the distiller is kept alive by a reference cycle"
+    finally:
+        gc.enable()
+    assert not any(k[2].startswith(scope) for k in L._ws_cache)
+    assert L.hip_last_error() == ""
+    with FusedDistiller(images, idx, _net(), graph=True, **kw) as f2:
+        got = []
+        for step in range(3):
+            got.append(f2.outer_step().item())
+            gc.collect()                        # in the middle of a multi-stream step sequence
+        assert got == want
+        scope2 = f2._scope
+    assert f2._closed and not any(k[2].startswith(scope2) for k in L._ws_cache)
+    f2.close()
+    with pytest.raises(RuntimeError):
+        f2.outer_step()
+    assert L.hip_last_error() == ""
+
+
 def test_split_real_batch_parts_add_up_to_the_whole_step():
     """Second sharding level on one GPU: two distillers take part 0 and part 1 of every class's sampled real batch (same seed, so the
     same permutations), weighted n_part / n and placed by the whole sample's minimum corner; part 1's flat buffer of partial real
