@@ -127,3 +127,12 @@ __device__ __forceinline__ bool resolve_chunk(int c, const int* __restrict__ gro
     }
     return false;
 }
+
+// ---- stream-K kernel gradient of the 128-channel convolution (conv_bww_sk.hip), called by dd3d_conv_bwd_weight (conv.hip) ----
+#define DD3D_BWW_WIN 512          // rows per window
+#define DD3D_BWW_MAX_TILES 3072   // G * 27 tiles whose step prefix fits the workgroup's LDS table ...
+#define DD3D_BWW_MAX_GROUPS 113   // ... i.e. at most this many groups (more: the row-chunk kernel)
+#define DD3D_BWW_MAX_NWG 1024     // persistent workgroups (partials: two [128 x 128] slabs each)
+int64_t conv128_bww_sk_ws_bytes(int64_t M_bound, int G);
+int conv128_bww_sk(const float* X, const float* dY, const int32_t* nbr, int64_t ld, int64_t M_bound, const int32_t* group_row_off, int G, float* dW, void* ws,
+                   int nwg, hipStream_t st);

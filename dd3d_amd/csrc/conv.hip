@@ -1029,7 +1029,12 @@ DD3D_API int64_t dd3d_conv_bwd_weight_ws_bytes(int64_t M_out, int G, int K, int 
     int64_t slots = Cin == 3 ? max_slots3(M_out, G) : max_slots128(M_out, G);
     int64_t nslab = (Cin == 3) ? slots : slots * K;
     int64_t per = (Cin == 3) ? (int64_t)K * 3 * Cout : (int64_t)Cin * Cout;
-    return align_up64(nslab * per * 4, 256) + align_up64(nslab * 4, 256) + 256;  // slabs, their flags, the mask of offsets present anywhere
+    const int64_t chunked = align_up64(nslab * per * 4, 256) + align_up64(nslab * 4, 256) + 256;  // slabs, their flags, the mask of offsets present anywhere
+    if (Cin == 128 && G <= DD3D_BWW_MAX_GROUPS) {  // the stream-K launch (conv_bww_sk.hip); the larger of the two while both forms exist
+        const int64_t sk = conv128_bww_sk_ws_bytes(M_out, G);
+        return sk > chunked ? sk : chunked;
+    }
+    return chunked;
 }
 
 // Y[M_out,Cout] = sum_k X[nbr[k'][o]] . Wmat[k],  k' = mirror ? K-1-k : k.   Wmat is [K,Cin,Cout] row-major.
@@ -1140,8 +1145,15 @@ DD3D_API int dd3d_conv_bwd_weight(const float* X, int Cin, const float* dY, int 
     float* slabs = (float*)ws;
     int* valid = (int*)((char*)ws + align_up64(nslab * per * 4, 256));
     unsigned* active = (unsigned*)((char*)valid + align_up64(nslab * 4, 256));
+    if (M_out > 0 && (!X || !dY || !nbr)) return DD3D_EARG;
+    static const int use_sk = getenv("DD3D_BWW_SK") ? atoi(getenv("DD3D_BWW_SK")) : 1;
+    if (Cin == 128 && use_sk && G <= DD3D_BWW_MAX_GROUPS && M_out > 0) {
+        // stream-K over the steps of all (group, offset) tiles: equal work per workgroup, accumulators resident across windows
+        static const int nwg_env = getenv("DD3D_BWW_NWG") ? atoi(getenv("DD3D_BWW_NWG")) : 512;
+        const int nwg = nwg_env < 8 ? 8 : nwg_env > DD3D_BWW_MAX_NWG ? DD3D_BWW_MAX_NWG : nwg_env / 8 * 8;
+        return conv128_bww_sk(X, dY, nbr, ld, M_out, group_row_off, G, dW, ws, nwg, st);
+    }
     if (M_out > 0) {
-        if (!X || !dY || !nbr) return DD3D_EARG;
         if (Cin == 3)
             k_conv3_bww<<<dim3((unsigned)slots), 256, 0, st>>>(X, dY, nbr, ld, group_row_off, G, slabs, valid);
         else

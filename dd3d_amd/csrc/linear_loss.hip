@@ -133,51 +133,108 @@ __global__ __launch_bounds__(256) void k_sl_bwd_x(const float* __restrict__ dl, 
     }
 }
 
-// grid (S, G): one workgroup per (site, group); 8 cloud-lanes x 32 float4 channel-lanes.  Only sites that some cloud of the group
-// occupies are written (the caller zero-fills the rest).  Cloud-lane partial sums are combined in lane order: deterministic.
+// grid (S, G): one workgroup per (site, group).  The clouds of the group that have a voxel at the site (about a fifth of them for
+// stroke digits) are first COMPACTED into an LDS list, in cloud order (one coalesced read of the table + a ballot scan: one memory
+// round trip); 8 row-lanes x 32 float4 channel-lanes then walk the list, row-lane r taking entries r, r + 8, ... with four row
+// gathers in flight, so a (site, group) costs two or three dependent round trips instead of two per four clouds.  The row-lanes are
+// combined in lane order: deterministic.  `zero_empty`: a site no cloud of the group occupies is written as zeros here (layouts with
+// the channels innermost: whole 512-byte rows); otherwise such sites are skipped and the caller zero-fills the buffer first.
 __global__ __launch_bounds__(256) void k_sl_bwd_w(const float* __restrict__ dl, const float* __restrict__ F, const int* __restrict__ vox_at, int S, int B,
-                                                  const int* __restrict__ group_cloud_off, int J, float* __restrict__ dWl, WStride ws) {
-    __shared__ f32x4 s_red[8 * 32];
-    const int s = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, c4 = tid & 31, bl = tid >> 5;
+                                                  const int* __restrict__ group_cloud_off, int J, float* __restrict__ dWl, WStride ws, int zero_empty) {
+    constexpr int LIST = 1024;  // clouds per compaction pass
+    __shared__ int s_v[LIST], s_b[LIST], s_wc[16];
+    __shared__ f32x4 s_red[4][8][32];
+    const int s = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, c4 = tid & 31, rl = tid >> 5;
     const int b0 = group_cloud_off[g], b1 = group_cloud_off[g + 1];
     const int* va = vox_at + (int64_t)s * B;
-    int any = 0;
-    for (int b = b0 + tid; b < b1; b += 256) any |= va[b] >= 0;
-    if (!__syncthreads_or(any)) return;
     const f32x4* F4 = (const f32x4*)F;
     float* out = dWl + g * ws.g + s * ws.s;
+    const bool unit_c = ws.c == 1;
+    bool any = false;
     for (int j0 = 0; j0 < J; j0 += 16) {
         f32x4 acc[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int bb = b0 + bl; bb < b1; bb += 32) {  // four clouds of this lane at a time: their table reads, then their row gathers, overlap
-            int vv[4];
-            f32x4 ff[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) vv[q] = bb + 8 * q < b1 ? va[bb + 8 * q] : -1;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) ff[q] = F4[(int64_t)max(vv[q], 0) * 32 + c4];
+        for (int base = b0; base < b1; base += LIST) {
+            // ---- the occupied clouds of [base, base + LIST), in cloud order ----
+            int v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                if (vv[q] < 0) continue;  // same clouds in the same order as a one-by-one walk
-                const float* d = dl + (int64_t)(bb + 8 * q) * J + j0;
+                const int b = base + q * 256 + tid;
+                v[q] = b < b1 ? va[b] : -1;
+            }
+            __syncthreads();  // the previous pass's list is no longer read
+            unsigned long long bal[4];
 #pragma unroll
-                for (int u = 0; u < 16; ++u)
-                    if (j0 + u < J) acc[u] += d[u] * ff[q];
+            for (int q = 0; q < 4; ++q) {
+                bal[q] = __ballot(v[q] >= 0);
+                if (lane == 0) s_wc[q * 4 + wid] = __popcll(bal[q]);
+            }
+            __syncthreads();
+            int n = 0, pos0[4];
+#pragma unroll
+            for (int x = 0; x < 16; ++x) {
+                const int c = s_wc[x];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (x == q * 4 + wid) pos0[q] = n;
+                n += c;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (v[q] >= 0) {
+                    const int pos = pos0[q] + __popcll(bal[q] & ((1ull << lane) - 1ull));
+                    s_v[pos] = v[q];
+                    s_b[pos] = base + q * 256 + tid;
+                }
+            __syncthreads();
+            any |= n > 0;
+            // ---- row-lane rl: entries rl, rl + 8, ...; four gathers in flight; added in list order ----
+            for (int i = rl; i < n; i += 32) {
+                int vv[4], bb[4];
+                f32x4 ff[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int iq = min(i + 8 * q, n - 1);
+                    vv[q] = s_v[iq], bb[q] = s_b[iq];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ff[q] = F4[(int64_t)vv[q] * 32 + c4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (i + 8 * q >= n) continue;
+                    const float* d = dl + (int64_t)bb[q] * J + j0;
+#pragma unroll
+                    for (int u = 0; u < 16; ++u)
+                        if (j0 + u < J) acc[u] += d[u] * ff[q];
+                }
             }
         }
+        if (!any && !zero_empty) return;  // (uniform) nothing at this site: the caller's zero fill stands
+        // ---- combine the 8 row-lanes: the two of a wave by a shuffle, the four waves through LDS, eight outputs per round ----
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            if (j0 + u >= J) break;
-            s_red[bl * 32 + c4] = acc[u];
+        for (int h8 = 0; h8 < 2; ++h8) {
+            if (j0 + h8 * 8 >= J) break;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                f32x4 a = acc[h8 * 8 + u], o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = __shfl_xor(a[e], 32, 64);
+                if (lane < 32) s_red[wid][u][c4] = a + o;  // row-lane 2w + row-lane 2w+1
+            }
             __syncthreads();
-            if (bl == 0) {
-                f32x4 t = s_red[c4];
+            {  // 8 outputs x 32 channel-lanes = one item per thread
+                const int u = tid >> 5, c = tid & 31;
+                if (j0 + h8 * 8 + u < J) {
+                    const f32x4 t = s_red[0][u][c] + s_red[1][u][c] + s_red[2][u][c] + s_red[3][u][c];
+                    float* o = out + (int64_t)(j0 + h8 * 8 + u) * ws.j;
+                    if (unit_c) {
+                        *(f32x4*)(o + c * 4) = t;
+                    } else {
 #pragma unroll
-                for (int q = 1; q < 8; ++q) t += s_red[q * 32 + c4];
-                float* o = out + (int64_t)(j0 + u) * ws.j;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[(int64_t)(c4 * 4 + e) * ws.c] = t[e];
+                        for (int e = 0; e < 4; ++e) o[(int64_t)(c * 4 + e) * ws.c] = t[e];
+                    }
+                }
             }
             __syncthreads();
         }
@@ -743,9 +800,12 @@ DD3D_API int dd3d_sparse_linear_bwd_w(const float* dl, const float* F, const int
                                       int J, float* dWl, const int64_t* strides, int64_t dWl_elems, void* stream) {
     if (G <= 0 || B < 0 || C != 128 || J <= 0 || S <= 0 || !strides || !dWl || !group_cloud_off || dWl_elems < (int64_t)J * C * S) return DD3D_EARG;
     hipStream_t st = (hipStream_t)stream;
-    DD3D_HIP(hipMemsetAsync(dWl, 0, dWl_elems * 4, st));
+    // channels innermost (the step's [G, J, S, C] layout): the kernel writes every (group, output, site) row itself, zeros included;
+    // otherwise (the parameter's own [J, C * S]: 4-byte stores a site count apart) empty sites are skipped over a zero-filled buffer
+    const int zero_empty = strides[2] == 1 && B > 0 && dl && F && vox_at && dWl_elems == (int64_t)G * J * C * S;
+    if (!zero_empty) DD3D_HIP(hipMemsetAsync(dWl, 0, dWl_elems * 4, st));
     if (!dl || !F || !vox_at) return DD3D_EARG;
-    if (B > 0) k_sl_bwd_w<<<dim3(S, G), 256, 0, st>>>(dl, F, vox_at, S, B, group_cloud_off, J, dWl, mk_stride(strides));
+    if (B > 0) k_sl_bwd_w<<<dim3(S, G), 256, 0, st>>>(dl, F, vox_at, S, B, group_cloud_off, J, dWl, mk_stride(strides), zero_empty);
     DD3D_CHECK_LAUNCH();
     return 0;
 }

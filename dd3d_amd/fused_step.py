@@ -130,8 +130,12 @@ class _Pass:
             gro1, gro2 = seg1[gidx].contiguous(), seg2[gidx].contiguous()   # rows of every group at tensor strides 1 and 2
         self._pre = (k0, p0, k1, p1, seg1, seg2, gro1, gro2)
 
-    def run(self, feats, labels, defer=False):
+    def run(self, feats, labels, defer=False, early=None):
         """Phase 2: (eager mode: ONE device->host read of the row counts, then) forward + first-order backward on the current stream.
+        ``early(pass, ev_l2)`` (optional): called once the input gradient of the 128-channel convolution is in the main stream's queue;
+        by then the side stream holds the classifier's gradients and the main stream has produced the second level's (event ``ev_l2``),
+        i.e. three of the four differentiable entries of gw exist.  FusedDistiller uses it to start the matching loss over them and the
+        second-order pass on the side stream, next to the rest of the first-order backward.
         ``defer`` (needs a stash): the two kernel gradients of the convolutions, which feed nothing but the loss VALUE, are not launched here;
         their operands are written into the stash, and FusedDistiller runs them next to the beginning of the following step."""
         stash = self.stash
@@ -241,7 +245,13 @@ class _Pass:
         # on a side stream next to the data-gradient chain (sparse linear -> pool/norm -> convolution bwd-data -> pool/norm).
         main, side = torch.cuda.current_stream(dev), self.side
 
+        # With an early second-order start the classifier's gradients and the hook's chain take the THIRD stream (ahead of the first layer's
+        # kernel gradient, which waits for the end of the first-order backward anyway), so that the 128-channel kernel gradient on the
+        # second stream does not queue behind that chain of small launches
+        cls_stream = self.cls_stream = self.side2 if (early is not None and os.environ.get("DD3D_SO_STREAM", "side2") == "side2") else side
+
         def classifier_gradients():
+            side = cls_stream
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 if self.dl_scale is not None:   # (the bias gradient of the SCALED logit gradients)
@@ -257,7 +267,7 @@ class _Pass:
         # The classifier's kernel gradient is bandwidth-bound and nothing needs it before the matching loss: started here it shares the
         # memory system with the norm / pool backward below (both take twice their time); started behind that (DD3D_CLSW_LATE, default)
         # it runs next to the matrix-bound input gradient of the convolution instead.
-        cls_late = os.environ.get("DD3D_CLSW_LATE", "1") != "0"
+        cls_late = os.environ.get("DD3D_CLSW_LATE", "1" if early is None else "0") != "0"
         if not cls_late:
             g_cw = classifier_gradients()
         gP1 = _empty((M2, 128), dev)
@@ -273,8 +283,12 @@ class _Pass:
         # pipe for ~200 us and the kernel gradient then overlaps the bandwidth-bound norm / pool backward and the second-order pass.
         if cls_late:
             g_cw = classifier_gradients()
-        after = os.environ.get("DD3D_BWW_AFTER", "1") != "0"
+        after = os.environ.get("DD3D_BWW_AFTER", "1" if early is None else "0") != "0"
         g_W1 = g_W0 = None
+        ev_l2 = None
+        if early is not None:   # the second level's gradients exist on the main stream from here on
+            ev_l2 = torch.cuda.Event()
+            ev_l2.record(main)
         if not after and not defer:
             side.wait_stream(main)
             with torch.cuda.stream(side):
@@ -285,16 +299,31 @@ class _Pass:
                    L.ptr(self.sched[2]), L.ptr(self.sched[3]), L.ptr(gP0), st)
         else:
             L.call("dd3d_conv_bwd_data", L.ptr(gY1), M1, c1, 128, L.ptr(W1t), 128, L.ptr(k1), ld1, 27, L.ptr(gP0), st)
-        if after and not defer:
+        # The hook's work goes onto the SIDE stream: behind the classifier's kernel gradient, which that stream computed itself, and in
+        # front of the 128-channel kernel gradient below; it runs next to the input gradient above (enqueued first: a HIP graph
+        # dispatches in capture order).  Only main <-> side waits, the patterns the capture already has (a third stream waiting for an
+        # event of the second crashed hipStreamEndCapture on ROCm 7.2).
+        self.early_out = None
+        if early is not None:
+            self.g_head = (g_w5, g_cw, g_cb)
+            self.early_out = early(self, ev_l2)
+        late = os.environ.get("DD3D_BWW_LATE", "0") != "0"   # (measurement) the 128-channel kernel gradient behind the norm / pool backward of level 1
+        if after and not defer and not late:
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 g_W1 = self._bww(P0, 128, gY1, k1, ld1, M1, gro2, seg2)
         gY0, g_w1, g_b1 = self._arp_inorm_bwd(gP0, arg0, cm.parent(2), self._rows(0), is0, w1, b1, seg1, M0, B, G, self.ga0, self.B_syn, True,
                                               dY_out=None if stash is None else stash["gY0"][:M0], gb_out=None if stash is None else stash["g_b1"])
+        if after and not defer and late:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                g_W1 = self._bww(P0, 128, gY1, k1, ld1, M1, gro2, seg2)
         # The first layer's kernel gradient feeds nothing but the loss VALUE either: it runs on a stream of its own next to the 128-channel
         # one (bandwidth-bound next to matrix-bound), and the main stream goes on to the matching loss of the differentiable entries and
         # the second-order pass (the caller joins the streams: FusedDistiller._compute)
         side2 = self.side2   # (queued behind the 128-channel kernel gradient on the same stream instead: 1.385 against 1.338 ms)
+        if os.environ.get("DD3D_W0_CHAIN", "0") != "0":   # (measurement)
+            side2 = self.side2 = side
         if not defer:
             side2.wait_stream(main)
             with torch.cuda.stream(side2):
@@ -355,12 +384,16 @@ class _Pass:
     def backward_to_points(self, G_w1, G_w5, G_cw, G_cb, per):
         """d(sum_g matching loss) / d feats [N_syn,3], given its gradients w.r.t. the four differentiable entries of gw_syn
         (each [Gs, ...]).  ``per`` = clouds per synthetic group."""
+        return self.backward_from_conv(self.backward_to_conv(G_w5, G_cw, G_cb, per), G_w1)
+
+    def backward_to_conv(self, G_w5, G_cw, G_cb, per):
+        """First part of backward_to_points: classifier, second norm / pool level and the second convolution's input gradient -- everything
+        that does not need the first level's gradient G_w1.  Returns hP0 [N_syn,128].  Runs on the current stream."""
         dev, Bs, Gs, J, S, Ns = self.dev, self.B_syn, self.Gs, self.J, self.S, max(self.N_syn, 1)
         k0, ld0, p0, pl0, k1, ld1, p1, pl1, seg1, seg2, gro1, gro2 = self.maps
         W0, W1, w1, b1, w5, b5 = self.params
         dp, cm, st = self.dp, self.cm, L.stream()
-        # rows of the synthetic clouds at strides 1 / 2 (device-side counts; their bound is the number of synthetic points)
-        m1s, m2s = seg1[Bs:].data_ptr(), seg2[Bs:].data_ptr()
+        m2s = seg2[Bs:].data_ptr()   # rows of the synthetic clouds at stride 2 (device-side count; its bound is the number of synthetic points)
         sst = _site_strides(J, 128, S)
         if _cw_site_major():   # the loss gradient already has the channels innermost: read through its strides, no layout launch
             Gsm, gst = G_cw, _cw_strides(J, 128, S)
@@ -383,6 +416,15 @@ class _Pass:
             L.call("dd3d_conv128_split", L.ptr(hY1), Ns, L.ptr(self.W1t), L.ptr(k1), ld1, 27, Ns, m2s, 1, L.ptr(hP0), L.ptr(ws), ws.numel(), st)
         else:
             L.call("dd3d_conv_bwd_data", L.ptr(hY1), Ns, m2s, 128, L.ptr(self.W1t), 128, L.ptr(k1), ld1, 27, L.ptr(hP0), st)
+        return hP0
+
+    def backward_from_conv(self, hP0, G_w1):
+        """Second part of backward_to_points: first norm / pool level (which takes G_w1), first convolution, voxel mean -> dfeats [N_syn,3]."""
+        dev, Bs, Gs, Ns = self.dev, self.B_syn, self.Gs, max(self.N_syn, 1)
+        k0, ld0, p0, pl0, k1, ld1, p1, pl1, seg1, seg2, gro1, gro2 = self.maps
+        W0, W1, w1, b1, w5, b5 = self.params
+        cm, st = self.cm, L.stream()
+        m1s = seg1[Bs:].data_ptr()   # rows of the synthetic clouds at stride 1
         hY0, _, _ = self._arp_inorm_bwd(hP0, self.arg0, cm.parent(2), self._rows(0), self.is0, w1, b1, seg1, Ns, Bs, Gs, None, 0, False, self.ga0, G_w1)
         hF0 = _empty((Ns, 3), dev)
         L.call("dd3d_conv_bwd_data", L.ptr(hY0), Ns, m1s, 128, L.ptr(W0), 3, L.ptr(k0), ld0, 27, L.ptr(hF0), st)
@@ -599,6 +641,7 @@ class FusedDistiller:
         self._graph = self._static = None
         self._graph_stamp, self._needs_eager, self._last_loss = None, False, None
         self._scope = "graph%x" % id(self)
+        self.so_early = os.environ.get("DD3D_SO_EARLY", "1") != "0"   # second-order pass started next to the first-order tail (_compute_gen)
         self._counters = _group_counters(dev, G + self.Gr)   # this distiller's own (its graphs keep the address)
         self._closed = False
 
@@ -922,7 +965,29 @@ class FusedDistiller:
                   dl_scale=self.dl_scale, gmin_floor=mb.get("gmin_floor"), max_per_group=max(ipc, int(mb.get("max_per") or mb["num_clouds"])),
                   flags=mb.get("flags"), counters=self._counters,
                   feats3=mb["features"].detach().contiguous() if os.environ.get("DD3D_MAPS_F0", "1") != "0" and mb["features"].shape[1] == 3 else None)
-        p.run(mb["features"], mb["labels"], defer=stash is not None)
+        # Second-order pass started early (DD3D_SO_EARLY, default on): of the four differentiable gradient entries only the first level's IN
+        # weight waits for the tail of the first-order backward (the input gradient of the 128-channel convolution and the norm / pool
+        # backward of level 1: ~260 us of matrix- and bandwidth-bound launches).  The loss over the other three and the second-order pass
+        # down to the second convolution -- a chain of ten small, latency-bound launches -- run on the side stream NEXT to those.
+        so_early = (stash is None and not self.split and self.dist_opt in ("ours", "modmse", "mse") and os.environ.get("DD3D_LOSS_SPLIT", "1") != "0"
+                    and self.so_early)
+        early = None
+        if so_early:
+            def early(ps, ev_l2):
+                sd = ps.cls_stream
+                sd.wait_event(ev_l2)
+                with torch.cuda.stream(sd):
+                    gs, gr = [t[:G] for t in ps.g_head], [t[G:] for t in ps.g_head]
+                    loss_a1, d3 = grouped_match_loss(gs, gr, self.dist_opt, G, [True] * 3)
+                    hP0 = ps.backward_to_conv(d3[0], d3[1], d3[2], ipc)
+                    ev_h = torch.cuda.Event()
+                    ev_h.record(sd)
+                if not static:   # allocated on the side stream, consumed on the main one
+                    cur = torch.cuda.current_stream(dev)
+                    loss_a1.record_stream(cur)
+                    hP0.record_stream(cur)
+                return loss_a1, hP0, ev_h
+        p.run(mb["features"], mb["labels"], defer=stash is not None, early=early)
         gw_syn, gw_real = [None if t is None else t[:G] for t in p.gw], [None if t is None else t[G:] for t in p.gw]
         # Only these entries of gw_syn depend on the synthetic points: IN weights, classifier weight and bias.  For the
         # layer-additive metrics the loss is split accordingly: the part over these four entries (with its gradient) runs on the main stream
@@ -952,6 +1017,18 @@ class FusedDistiller:
             dfeats = p.backward_to_points(d4[0], d4[1], d4[2], d4[3], ipc)
             main.wait_stream(side)   # the classifier gradients' stream (and whatever else the caller put there) joins before the update
             loss_g = loss_a
+        elif so_early:
+            loss_a1, hP0, ev_h = p.early_out
+            loss_a2, d1 = grouped_match_loss([gw_syn[1]], [gw_real[1]], self.dist_opt, G, [True])   # the first level's IN weight
+            side.wait_stream(p.side2)
+            with torch.cuda.stream(side):
+                loss_b, _ = grouped_match_loss([gw_syn[i] for i in const], [gw_real[i] for i in const], self.dist_opt, G, [False] * 4)
+            main.wait_event(ev_h)
+            dfeats = p.backward_from_conv(hP0, d1[0])
+            main.wait_stream(side)
+            if not static:
+                loss_b.record_stream(main)
+            loss_g = loss_a1 + loss_a2 + loss_b
         elif self.dist_opt in ("ours", "modmse", "mse") and os.environ.get("DD3D_LOSS_SPLIT", "1") != "0":
             main.wait_event(p.ev_cls)
             loss_a, d4 = grouped_match_loss([gw_syn[i] for i in diff], [gw_real[i] for i in diff], self.dist_opt, G, [True] * 4)

@@ -417,6 +417,46 @@ def test_sparse_linear_closed_under_differentiation():
     assert rel_err(hf, qf) < 5e-5 and rel_err(hw, qw) < 5e-5
 
 
+@pytest.mark.parametrize("B,J,gco", [(40, 10, [0, 7, 7, 25, 40]), (1300, 10, [0, 1100, 1300]), (30, 40, [0, 30])])
+def test_sparse_linear_bwd_w_layouts_groups_and_long_lists(B, J, gco):
+    """dd3d_sparse_linear_bwd_w (compacted cloud lists) against a dense fp64 reference per group: the parameter layout [G, J, C*S] (zero
+    fill + occupied sites) and the step's [G, J, S, C] layout (every row written by the kernel, no fill); an empty group, a group of
+    more clouds than one compaction pass (1024), more outputs than one register pass (16); both layouts agree bit for bit."""
+    from dd3d_amd import _lib as L
+    from dd3d_amd.ops import DensePlacement, _param_strides
+    import ctypes
+    d = dev()
+    coords = make_coords(B=B, pts=60, extent=28, seed=B)
+    cm = manager(coords, B)
+    G = len(gco) - 1
+    gco_t = torch.tensor(gco, dtype=torch.int32, device=d)
+    cg = torch.bucketize(torch.arange(B), torch.tensor(gco[1:]), right=True).clamp(max=G - 1).to(torch.int32).to(d)
+    dp = DensePlacement(cm, 4, (1, 28, 28), cg, G, gco_t)
+    cm.sync()
+    M2, S, C = cm.num_rows(4), dp.S, 128
+    g = torch.Generator().manual_seed(3)
+    F0 = torch.randn(M2, C, generator=g)
+    dl = torch.randn(B, J, generator=g)
+    f, dd = F0.to(d), dl.to(d)
+    outs = {}
+    for name, strides, shape in (("param", _param_strides(J, C, S), (G, J, C, S)), ("site", (ctypes.c_int64 * 4)(J * C * S, C * S, 1, C), (G, J, S, C))):
+        dW = torch.full(shape, 7.0, device=d)
+        L.call("dd3d_sparse_linear_bwd_w", L.ptr(dd), L.ptr(f), L.ptr(dp.vox_at), S, B, L.ptr(gco_t), G, C, J, L.ptr(dW), strides, dW.numel(), L.stream())
+        outs[name] = dW if name == "param" else dW.permute(0, 1, 3, 2).contiguous()
+    assert torch.equal(outs["param"], outs["site"])
+    site = dp.site[:M2].cpu().long()
+    cloud = cm.coordinates(4)[:, 0].cpu().long()
+    ref = torch.zeros(G, J, C, S, dtype=torch.float64)
+    for gi in range(G):
+        rows = torch.nonzero((cloud >= gco[gi]) & (cloud < gco[gi + 1])).reshape(-1)
+        if rows.numel():
+            contrib = dl.double()[cloud[rows]][:, :, None] * F0.double()[rows][:, None, :]     # [n, J, C]
+            ref[gi].index_add_(2, site[rows], contrib.permute(1, 2, 0))
+        else:
+            assert float(outs["param"][gi].abs().max()) == 0.0
+    assert rel_err(outs["param"], ref) < 2e-5
+
+
 def test_dense_out_of_extent_is_an_error():
     from dd3d_amd.ops import DensePlacement
     coords = torch.tensor([[0, 0, 0.0, 0.0], [0, 0, 0.0, 200.0]])

@@ -41,6 +41,8 @@ logits, dl = torch.empty(B, J, device=dev), R(B, J)
 gP1 = R(M2, 128)
 gP0, gY0, gY1, dW1, dW0 = R(M1, 128), torch.empty(M0, 128, device=dev), R(M1, 128), torch.empty(G, 27, 128, 128, device=dev), torch.empty(G, 27, 3, 128, device=dev)
 gw_w, gw_b = torch.empty(G, 128, device=dev), torch.empty(G, 128, device=dev)
+import ctypes
+gcw, cwst = torch.empty(G, J, S, 128, device=dev), (ctypes.c_int64 * 4)(J * 128 * S, 128 * S, 1, 128)
 st = L.stream()
 ws = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
 nbr_tmp = torch.empty_like(k0)
@@ -58,6 +60,7 @@ K = {
  "arp_fwd L2": (lambda: L.call("dd3d_affine_relu_pool_fwd", L.ptr(xh1), L.ptr(w), L.ptr(bb), 1, 128, L.ptr(p1), pl1, 8, M2, None, L.ptr(P1), L.ptr(arg1), st), 512 * M1 + 1024 * M2),
  "sl_fwd": (lambda: sl_fwd_call(P1, dp, None, Wsm, sst, J, None, logits), 512 * M2 * (1 + J)),
  "sl_bwd_x": (lambda: sl_bwd_x_call(dl, dp, None, Wsm, sst, J, 0, P1), 512 * M2 * (1 + J)),
+ "sl_bwd_w": (lambda: L.call("dd3d_sparse_linear_bwd_w", L.ptr(dl), L.ptr(P1), L.ptr(dp.vox_at), S, B, L.ptr(gco), G, 128, J, L.ptr(gcw), cwst, gcw.numel(), st), 512 * M2 + 4 * S * B + 4 * G * J * S * 128),
  "arp_inorm_bwd L1": (lambda: L.call("dd3d_arp_inorm_bwd", L.ptr(gP0), L.ptr(arg0), L.ptr(cm.parent(2)), L.ptr(xh0), L.ptr(is0), L.ptr(w), L.ptr(bb), 128, L.ptr(seg1), B,
                                      L.ptr(cg), L.ptr(gco), G, L.ptr(gY0), None, 0, None, None, L.ptr(gw_w), L.ptr(gw_b), L.ptr(ws), ws.numel(), st), 1024 * M0 + 1024 * M1),
  "arp_inorm_bwd L2": (lambda: L.call("dd3d_arp_inorm_bwd", L.ptr(gP1), L.ptr(arg1), L.ptr(cm.parent(4)), L.ptr(xh1), L.ptr(is1), L.ptr(w), L.ptr(bb), 128, L.ptr(seg2), B,
