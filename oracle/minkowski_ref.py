@@ -418,12 +418,57 @@ class MinkowskiInstanceNorm(nn.Module):
         return f"MinkowskiInstanceNorm(nchannels={self.num_features})"
 
 
+# ---- test hook: ReLU / max-pool on branches somebody else took -------------------------------------------------------------
+# ReLU followed by max-pool is piecewise linear: which child row wins and whether the winner is positive.  With 27 M ReLU inputs per
+# cfg2 step, once in a few steps an fp32 pre-activation lies within rounding of zero (or two candidates tie) and an fp32 device
+# takes the OTHER branch than this fp64 restatement; the gradients then differ by a jump, not by rounding.  To check such a step to
+# the same tolerance as every other, the test replays this restatement ON THE DEVICE'S BRANCHES: inside ``forced_branches`` every
+# MinkowskiReLU passes its input through and the i-th MinkowskiMaxPooling call computes out[o][c] = x[arg_i[o][c]][c] if mask_i[o][c]
+# else 0 (backward: the gradient goes to that row, nowhere else) -- the same opaque Function structure as MaxPoolFn.
+_FORCED: Optional[list] = None
+
+
+class forced_branches:
+    def __init__(self, branches):
+        self.branches = list(branches)   # [(arg [M_out, C] int64 rows of the pooled level's input, mask [M_out, C] bool), ...] in call order
+
+    def __enter__(self):
+        global _FORCED
+        assert _FORCED is None
+        _FORCED = list(self.branches)
+        return self
+
+    def __exit__(self, *exc):
+        global _FORCED
+        left, _FORCED = _FORCED, None
+        if exc[0] is None:
+            assert not left, "fewer pooling calls than forced branch sets"
+
+
+class ForcedReluPoolFn(Function):
+    @staticmethod
+    def forward(ctx, X, arg, mask):
+        ctx.save_for_backward(arg, mask)
+        ctx.Mi = X.shape[0]
+        return torch.where(mask, X.gather(0, arg), torch.zeros((), dtype=X.dtype))
+
+    @staticmethod
+    def backward(ctx, g):
+        arg, mask = ctx.saved_tensors
+        with torch.no_grad():
+            dX = torch.zeros(ctx.Mi, g.shape[1], dtype=g.dtype)
+            dX.scatter_add_(0, arg, torch.where(mask, g, torch.zeros_like(g)))
+        return dX, None, None
+
+
 class MinkowskiReLU(nn.Module):
     def __init__(self, inplace=False):
         super().__init__()
         self.relu = nn.ReLU(inplace=inplace)
 
     def forward(self, x: SparseTensor):
+        if _FORCED is not None:   # the sign is applied by the pooling call that follows (forced_branches)
+            return SparseTensor(x.F, x.C, x.tensor_stride, x.coordinate_manager)
         return SparseTensor(self.relu(x.F), x.C, x.tensor_stride, x.coordinate_manager)
 
     def __repr__(self):
@@ -441,6 +486,12 @@ class MinkowskiMaxPooling(nn.Module):
         cm = x.coordinate_manager
         Cout = cm.get_stride_map(ts, ts * self.stride)
         kids = cm.get_kernel_map(ts, ts * self.stride, self.kernel_size)
+        if _FORCED is not None:
+            arg, mask = _FORCED.pop(0)
+            assert arg.shape == (Cout.shape[0], x.F.shape[1]) and mask.shape == arg.shape
+            # the forced row must be a child of the pooled voxel: a branch the pooling window really has
+            assert bool(((kids.t()[:, :, None] == arg[:, None, :]).any(1)).all()), "forced arg-max row is not a child of its pooled voxel"
+            return SparseTensor(ForcedReluPoolFn.apply(x.F, arg, mask), Cout, ts * self.stride, cm)
         out, _ = MaxPoolFn.apply(x.F, kids)
         return SparseTensor(out, Cout, ts * self.stride, cm)
 

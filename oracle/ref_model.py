@@ -167,19 +167,21 @@ def clamp_synthetic_(image_syn: torch.Tensor):
 
 
 def matching_step(network, image_syn, real_images_per_class, ipc, dist_opt="modmse", pyt=False,
-                  optimizer=None, num_points=250, quantization_size=1):
+                  optimizer=None, num_points=250, quantization_size=1, class_ids=None):
     """mnist_distill.py:333-369 for one iteration.
 
     real_images_per_class[c]: {0,1} float tensor [n_c,1,28,28] (the already-sampled real batch of class c), or -- for the
     point-cloud configs -- a list of [n_i,3] float clouds (coordinates = features = the points, as Mnist2Dreal does with pixels).
     image_syn: leaf tensor [num_classes*ipc, num_points, 3] with requires_grad=True.
+    class_ids (optional): the label of every entry of real_images_per_class (default: its position) -- a subset of the classes on its own.
     Returns dict(loss, per_class, gw_real, gw_syn (detached), grad) and applies optimizer.step() if given."""
     criterion = nn.CrossEntropyLoss()
     params = list(network.parameters())
     loss = torch.tensor(0.0, dtype=image_syn.dtype)
     per_class, gws_all, gwr_all, logits_all = [], [], [], []
     for c, imgs in enumerate(real_images_per_class):
-        labels = torch.full((len(imgs),), c, dtype=torch.long)
+        cid = c if class_ids is None else int(class_ids[c])
+        labels = torch.full((len(imgs),), cid, dtype=torch.long)
         if torch.is_tensor(imgs):
             batch = collate([real_item(imgs[i], labels[i], num_points) for i in range(imgs.shape[0])])
         else:
@@ -190,7 +192,7 @@ def matching_step(network, image_syn, real_images_per_class, ipc, dist_opt="modm
         loss_real = criterion(out, batch["labels"])
         gw_real = [g.detach().clone() for g in torch.autograd.grad(loss_real, params)]
         syn = image_syn[c * ipc:(c + 1) * ipc]
-        lab = torch.full((ipc,), c, dtype=torch.long)
+        lab = torch.full((ipc,), cid, dtype=torch.long)
         items = [{"coordinates": syn[i], "features": syn[i], "label": lab[i]} for i in range(ipc)]
         c_, f_, l_ = ME.sparse_collate([d["coordinates"] for d in items], [d["features"] for d in items],
                                        [d["label"].reshape(1) for d in items], dtype=image_syn.dtype)

@@ -354,11 +354,33 @@ def _discontinuity_classes(f, feats, tol=2e-6):
     return sorted({g % G for g in g0 | g1})
 
 
-def _graph_steps_vs_oracle(f, images, idx, rng, onet, ipc, per, metric, steps, tol=1e-4):
+def _oracle_on_device_branches(f, onet, osyn, reals, c, ipc, metric):
+    """The fp64 oracle's step for class ``c`` alone, replayed on the branches the DEVICE took (oracle.minkowski_ref.forced_branches): the
+    arg-max row of every pooled voxel and channel and whether its value passed the ReLU, read from the pass's own buffers (arg0 / arg1,
+    P0 / P1 > 0), for the real and the synthetic batch of the class.  ReLU + max-pool restricted to a branch is linear, so on these branches
+    the device's loss and gradients must agree with fp64 to the same tolerance as everywhere else."""
+    from oracle import minkowski_ref as ME
+    p, G = f.last["passes"][0], f.G
+    gi = f.classes.index(c)
+    gro1, gro2 = p.maps[10].cpu().long(), p.maps[11].cpu().long()
+    gro4 = p.dp.seg_off.cpu().long()[p.gco.cpu().long()]
+    sets = {}
+    for g in (G + gi, gi):   # the real batch runs first (mnist_distill.py:337-350), then the synthetic one
+        a0, a1, b0, b1, c0, c1 = int(gro1[g]), int(gro1[g + 1]), int(gro2[g]), int(gro2[g + 1]), int(gro4[g]), int(gro4[g + 1])
+        arg0, arg1 = p.arg0[b0:b1].cpu().long() - a0, p.arg1[c0:c1].cpu().long() - b0
+        assert int(arg0.min()) >= 0 and int(arg0.max()) < a1 - a0 and int(arg1.min()) >= 0 and int(arg1.max()) < b1 - b0
+        sets[g] = [(arg0, p.P0[b0:b1].cpu() > 0), (arg1, p.P1[c0:c1].cpu() > 0)]
+    o = osyn.detach()[c * ipc:(c + 1) * ipc].clone().requires_grad_()
+    with ME.forced_branches(sets[G + gi] + sets[gi]):
+        return R.matching_step(onet, o, [reals[gi]], ipc, metric, False, class_ids=[c])
+
+
+def _graph_steps_vs_oracle(f, images, idx, rng, onet, ipc, per, metric, steps, tol=1e-4, replay=()):
     """Run ``steps`` steps of a graph-mode FusedDistiller (step 0 = the bound-sized eager body, step 1 = capture + replay, then replays);
     before each one the fp64 oracle takes the same synthetic points and the same sample (same RandomState stream) and computes the loss
-    and the xyz gradient of mnist_distill.py:333-365.  Classes that sit on a ReLU / arg-max discontinuity in this step (see
-    _discontinuity_classes; at most one per step) are compared at 1e-2 on the loss instead; all others within ``tol``."""
+    and the xyz gradient of mnist_distill.py:333-365.  All classes within ``tol`` -- a class that sits on a ReLU / arg-max discontinuity
+    in this step (see _discontinuity_classes; at most one per step) against the oracle REPLAYED ON THE DEVICE'S BRANCHES
+    (_oracle_on_device_branches: loss, xyz gradient and all eight gw entries), and at 1e-2 on the loss against the plain oracle."""
     out = []
     G = f.G
     for step in range(steps):
@@ -381,6 +403,18 @@ def _graph_steps_vs_oracle(f, images, idx, rng, onet, ipc, per, metric, steps, t
               f"xyz-grad {e_grad:.2e}" + (f"; class {skip} on a ReLU/arg-max discontinuity, loss rel {rel_err(pc[skip], rpc[skip]):.1e}" if skip else ""))
         assert e_loss < tol and e_pc < tol and e_grad < tol
         assert not skip or rel_err(pc[skip], rpc[skip]) < 1e-2
+        # ... and on the device's own branches that class meets the tolerance of all others: loss, xyz gradient, every gw entry
+        # (``replay``: classes replayed that way in any case -- off a discontinuity the forced branches are the oracle's own)
+        for c in sorted(set(skip) | set(replay)):
+            fr = _oracle_on_device_branches(f, onet, osyn, [images[o] for o in order], f.classes[c], ipc, metric)
+            crow = torch.arange(f.classes[c] * ipc, (f.classes[c] + 1) * ipc)
+            if c not in skip:
+                assert rel_err(fr["per_class"], rpc[c:c + 1]) < 1e-9 and rel_err(fr["grad"], ref["grad"][crow]) < 1e-9
+            e_l, e_g = rel_err(pc[c:c + 1], fr["per_class"]), rel_err(f.last["grad"][crow.to(DEV)], fr["grad"])
+            e_w = max(max(rel_err(f.last["gw_real"][i][c].reshape(-1), fr["gw_real"][0][i].reshape(-1)),
+                          rel_err(f.last["gw_syn"][i][c].reshape(-1), fr["gw_syn"][0][i].reshape(-1))) for i in range(8))
+            print(f"   class {c} replayed in fp64 on the device's ReLU / arg-max branches: loss rel {e_l:.2e}, xyz-grad {e_g:.2e}, gw lists {e_w:.2e}")
+            assert e_l < tol and e_g < tol and e_w < tol
         if step == 0 and not skip:   # the SGD update itself (momentum buffer starts at zero)
             before.clamp_(0, 27)
             before[:, :, 0] = 0
@@ -418,7 +452,7 @@ def test_cfg3_shaped_graph_step_vs_oracle():
     images, _, idx = mnist3d_like(10, 32, seed=1)
     f = FusedDistiller(images, idx, _net(), ipc=50, batch_size=32, device=DEV, seed=3, image_syn=init_synthetic(10, 50, 250, seed=2), graph=True)
     assert 10 * 50 * 250 > SPLIT_MAX_ROWS
-    _graph_steps_vs_oracle(f, images, idx, np.random.RandomState(3), _oracle_net(), 50, 32, "modmse", 2)
+    _graph_steps_vs_oracle(f, images, idx, np.random.RandomState(3), _oracle_net(), 50, 32, "modmse", 2, replay=(0, 7))
     assert f._graph is not None
 
 

@@ -172,27 +172,41 @@ def test_batch_from_images_equals_per_item_collate():
 
 def test_report_table2_anchor_over_1250_iterations():
     """Report Table 2's protocol on the GPU path (1 synthetic cloud per class, Kaiming init, 1250 iterations, MinkowskiEngine layers):
-    mean |gradient| on the synthetic xyz averaged over the run, against the report's 4e-4 (layer-wise cosine) and 0.033 (sum of squares),
-    within a decade -- stroke digits stand in for MNIST, so this is an anchor for the unpinned MinkowskiEngine semantics, not a parity
-    bound.  Iteration 0 is also compared with the CPU oracle's value (tests/test_oracle_golden.py)."""
+    mean |gradient| on the synthetic xyz (mnist_distill.py:367) against the report's 4e-4 (layer-wise cosine) and 0.033 (sum of squares).
+    Stroke digits stand in for MNIST, so this is an anchor for the unpinned MinkowskiEngine semantics, not a parity bound; the factors were
+    taken apart one at a time (tools/table2.py, tools/table2_decay.py):
+      * SURVEY.md section 6's 0.039 (its own restatement, ipc 10, iteration 0) is REPRODUCED: 0.0396 -- asserted here to 5 %;
+      * at the report's ipc 1 the same quantity is 0.55 at iteration 0 (x14: the cloud's gradient is no longer a mean over ten clouds) and
+        decays to 0.15 averaged over 1250 iterations (0.08 at the end of the reference's 2500); Kaiming seed, synthetic seed, real batch
+        size and stroke density move it by +-2 % / 2 % / 4 % / -13 % -- the remaining factor 4.6 to the report's 0.033 is not explained by
+        anything that can be varied offline (MNIST itself cannot): asserted as a band around the measured factor, not a decade;
+      * the layer-wise cosine sits 19 % above the report (6 % at MNIST-like stroke density): asserted within 40 %."""
     from dd3d_amd.fused_step import FusedDistiller
     from dd3d_amd.models.MEConv import MEConvExp
     from dd3d_amd.synthetic import mnist3d_like
     images, _, idx = mnist3d_like(10, 256, seed=0)
     got = {}
-    for metric, report in (("ours", 4e-4), ("modmse", 0.033)):
+    for metric, report, lo, hi in (("ours", 4e-4, 0.9, 1.4), ("modmse", 0.033, 3.0, 6.5)):
         torch.manual_seed(0)
         net = MEConvExp(in_channel=3, out_channel=10).to(DEV).train()
-        f = FusedDistiller(images, idx, net, ipc=1, device=DEV, seed=1, image_syn=init_synthetic(10, 1, 250, seed=0), dist_opt=metric, graph=True)
-        acc = torch.zeros((), device=DEV, dtype=torch.float64)
-        first = None
-        for it in range(1250):
-            f.outer_step()
-            m = f.last["grad"].abs().mean()
-            first = float(m) if it == 0 else first
-            acc += m.double()
-        f.check()
+        with FusedDistiller(images, idx, net, ipc=1, device=DEV, seed=1, image_syn=init_synthetic(10, 1, 250, seed=0), dist_opt=metric, graph=True) as f:
+            acc = torch.zeros((), device=DEV, dtype=torch.float64)
+            first = None
+            for it in range(1250):
+                f.outer_step()
+                m = f.last["grad"].abs().mean()
+                first = float(m) if it == 0 else first
+                acc += m.double()
+            f.check()
         got[metric] = (first, float(acc) / 1250)
-        print(f"{metric}: mean |xyz-grad| iteration 0 {first:.3e}, average over 1250 iterations {got[metric][1]:.3e} (report {report})")
-        assert report / 10 < got[metric][1] < report * 10
+        print(f"{metric}: mean |xyz-grad| iteration 0 {first:.3e}, average over 1250 iterations {got[metric][1]:.3e} (report {report}: x{got[metric][1] / report:.2f})")
+        assert report * lo < got[metric][1] < report * hi
     assert got["ours"][0] == pytest.approx(4.92e-4, rel=0.05) and got["modmse"][0] == pytest.approx(0.552, rel=0.05)   # the oracle's iteration 0
+    # SURVEY.md section 6: "mean |xyz-grad| for sum-of-squares came out at 0.039" -- its configuration was ipc 10, first iteration
+    torch.manual_seed(0)
+    net = MEConvExp(in_channel=3, out_channel=10).to(DEV).train()
+    with FusedDistiller(images, idx, net, ipc=10, device=DEV, seed=1, image_syn=init_synthetic(10, 10, 250, seed=0), dist_opt="modmse", graph=False) as f:
+        f.outer_step()
+        v = float(f.last["grad"].abs().mean())
+    print(f"modmse, ipc 10, iteration 0: {v:.4f} (SURVEY.md section 6: 0.039)")
+    assert v == pytest.approx(0.039, rel=0.05)
