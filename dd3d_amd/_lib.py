@@ -186,3 +186,14 @@ def workspace(nbytes: int, device, tag: str = "ws") -> torch.Tensor:
         t = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
         _ws_cache[key] = t
     return t
+
+
+def true_divide(t: torch.Tensor, q: float) -> torch.Tensor:
+    """t / q as the reference computes coordinates / quantization_size (models/MEConv.py:262 divides HOST tensors: a correctly rounded
+    fp32 division).  torch's device kernel for ``tensor / python_scalar`` multiplies by the rounded reciprocal instead, which moves a
+    point that lies within an ulp of a voxel face into the neighbouring voxel whenever the voxel size is not a power of two; dividing
+    by a 0-d DEVICE tensor takes the true-division kernel.  The HIP kernels that build coordinates (dd3d_assemble_batch,
+    dd3d_gather_clouds, dd3d_syn_head) divide the same way, so the eager and the captured step quantise identically."""
+    if q == 1.0:
+        return t.clone()
+    return torch.div(t, torch.tensor(q, dtype=t.dtype, device=t.device))

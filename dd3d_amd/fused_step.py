@@ -764,7 +764,7 @@ class FusedDistiller:
             n, dev = int(off.numel()) - 1, self.device
             cnt = (off[1:] - off[:-1]).long()
             seg = torch.repeat_interleave(torch.arange(n, device=dev), cnt)
-            vox = torch.floor(xyz[:int(off[-1])] / self.quant)
+            vox = torch.floor(L.true_divide(xyz[:int(off[-1])], self.quant))
             mn = torch.full((n, 3), float("inf"), device=dev).scatter_reduce_(0, seg[:, None].expand(-1, 3), vox, "amin")
             c = torch.floor(mn / 4) * 4
             c[torch.isinf(c)] = float(0x7F7F7F7F)   # a cloud without points has no corner
@@ -807,7 +807,7 @@ class FusedDistiller:
         b = torch.repeat_interleave(torch.arange(ids.numel(), device=dev), cnt)
         rows = start[b] + (torch.arange(int(pt[-1]), device=dev) - pt[b])
         p = xyz[rows]
-        return {"coordinates": torch.cat([b[:, None].to(_F32), p / self.quant], 1), "features": p.clone(), "num_clouds": int(ids.numel()),
+        return {"coordinates": torch.cat([b[:, None].to(_F32), L.true_divide(p, self.quant)], 1), "features": p.clone(), "num_clouds": int(ids.numel()),
                 "labels": torch.tensor(np.repeat(self.real_classes, sizes), device=dev), "pt_off": pt.to(_I32),
                 "cloud_group": torch.tensor(np.repeat(np.arange(self.Gr), sizes), device=dev, dtype=_I32),
                 "group_cloud_off": torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), device=dev, dtype=_I32), "max_per": int(max(sizes))}
@@ -817,7 +817,7 @@ class FusedDistiller:
         labels = torch.tensor(np.repeat(self.real_classes, sizes), device=dev)
         b = batch_from_images(images, labels, self.num_points)
         if self.quant != 1.0:
-            b["coordinates"][:, 1:] /= self.quant
+            b["coordinates"][:, 1:] = L.true_divide(b["coordinates"][:, 1:], self.quant)
         b["cloud_group"] = torch.tensor(np.repeat(np.arange(self.Gr), sizes), device=dev, dtype=_I32)
         b["group_cloud_off"] = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), device=dev, dtype=_I32)
         b["max_per"] = int(max(sizes))
@@ -891,7 +891,7 @@ class FusedDistiller:
         if pt is None:
             cnt = torch.bincount(rb["coordinates"][:, 0].long(), minlength=int(rb["num_clouds"]))
             pt = torch.cat([cnt.new_zeros(1), torch.cumsum(cnt, 0)]).to(_I32)
-        return {"coordinates": torch.cat([torch.cat([self.syn_batch_col, xyz / self.quant], 1), rc]), "features": torch.cat([xyz, rb["features"]]),
+        return {"coordinates": torch.cat([torch.cat([self.syn_batch_col, L.true_divide(xyz, self.quant)], 1), rc]), "features": torch.cat([xyz, rb["features"]]),
                 "labels": torch.cat([self.syn_labels, rb["labels"].to(_I32)]), "num_clouds": Bs + int(rb["num_clouds"]),
                 "cloud_group": torch.cat([self.syn_group, rb["cloud_group"] + G]),
                 "group_cloud_off": torch.cat([self.syn_gco, rb["group_cloud_off"][1:] + Bs]),

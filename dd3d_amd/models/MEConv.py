@@ -191,10 +191,13 @@ class MEPytorch(ME.MinkowskiNetwork):
         return self.classifier(out.view(out.size(0), -1))
 
 
+from .._lib import true_divide as _true_divide
+
 def create_input_batch(batch, is_minknet, device="cuda", quantization_size=0.05):
     """models/MEConv.py:260-269: divides the spatial columns IN PLACE, then wraps the batch in a TensorField on ``device``."""
     if is_minknet:
-        batch["coordinates"][:, 1:] = batch["coordinates"][:, 1:] / quantization_size
+        # a correctly rounded division, as the reference's host-side ``/=`` is (torch's device kernel for tensor / scalar is not: _lib.true_divide)
+        batch["coordinates"][:, 1:] = _true_divide(batch["coordinates"][:, 1:], float(quantization_size))
         return TensorField(coordinates=batch["coordinates"], features=batch["features"], device=device,
                            num_clouds=batch.get("num_clouds"))
     return batch["coordinates"].permute(0, 2, 1).to(device)

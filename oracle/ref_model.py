@@ -38,10 +38,17 @@ def collate(items: Sequence[Dict[str, torch.Tensor]]) -> Dict[str, torch.Tensor]
     return {"coordinates": c, "features": f, "labels": l}
 
 
-def create_input_batch(batch, is_minknet=True, device="cpu", quantization_size=0.05):
-    """models/MEConv.py:260-269 (in-place division of the spatial columns, then a TensorField)."""
+def create_input_batch(batch, is_minknet=True, device="cpu", quantization_size=0.05, coord_dtype=None):
+    """models/MEConv.py:260-269 (in-place division of the spatial columns, then a TensorField).
+    coord_dtype (optional, for an fp64 run of this restatement): the dtype the division is carried out in.  The reference divides fp32
+    coordinates in fp32; a point within rounding of a voxel face can land in the neighbouring voxel when the same quotient is taken in
+    fp64 -- with torch.float32 here the integer voxel coordinates are the reference's while everything after them stays fp64."""
     assert is_minknet
-    batch["coordinates"][:, 1:] = batch["coordinates"][:, 1:] / quantization_size
+    c = batch["coordinates"][:, 1:]
+    if coord_dtype is not None and coord_dtype != c.dtype:
+        batch["coordinates"][:, 1:] = (c.to(coord_dtype) / quantization_size).to(c.dtype)
+    else:
+        batch["coordinates"][:, 1:] = c / quantization_size
     return ME.TensorField(coordinates=batch["coordinates"], features=batch["features"], device=device)
 
 
@@ -167,12 +174,13 @@ def clamp_synthetic_(image_syn: torch.Tensor):
 
 
 def matching_step(network, image_syn, real_images_per_class, ipc, dist_opt="modmse", pyt=False,
-                  optimizer=None, num_points=250, quantization_size=1, class_ids=None):
+                  optimizer=None, num_points=250, quantization_size=1, class_ids=None, coord_dtype=None):
     """mnist_distill.py:333-369 for one iteration.
 
     real_images_per_class[c]: {0,1} float tensor [n_c,1,28,28] (the already-sampled real batch of class c), or -- for the
     point-cloud configs -- a list of [n_i,3] float clouds (coordinates = features = the points, as Mnist2Dreal does with pixels).
     image_syn: leaf tensor [num_classes*ipc, num_points, 3] with requires_grad=True.
+    coord_dtype: see create_input_batch.
     class_ids (optional): the label of every entry of real_images_per_class (default: its position) -- a subset of the classes on its own.
     Returns dict(loss, per_class, gw_real, gw_syn (detached), grad) and applies optimizer.step() if given."""
     criterion = nn.CrossEntropyLoss()
@@ -188,7 +196,7 @@ def matching_step(network, image_syn, real_images_per_class, ipc, dist_opt="modm
             batch = collate([syn_item(imgs[i][:num_points], labels[i]) for i in range(len(imgs))])
         batch["coordinates"] = batch["coordinates"].to(image_syn.dtype)
         batch["features"] = batch["features"].to(image_syn.dtype)
-        out = network(create_input_batch(batch, True, device="cpu", quantization_size=quantization_size))
+        out = network(create_input_batch(batch, True, device="cpu", quantization_size=quantization_size, coord_dtype=coord_dtype))
         loss_real = criterion(out, batch["labels"])
         gw_real = [g.detach().clone() for g in torch.autograd.grad(loss_real, params)]
         syn = image_syn[c * ipc:(c + 1) * ipc]
@@ -197,7 +205,7 @@ def matching_step(network, image_syn, real_images_per_class, ipc, dist_opt="modm
         c_, f_, l_ = ME.sparse_collate([d["coordinates"] for d in items], [d["features"] for d in items],
                                        [d["label"].reshape(1) for d in items], dtype=image_syn.dtype)
         sbatch = {"coordinates": c_, "features": f_, "labels": l_}
-        out_s = network(create_input_batch(sbatch, True, device="cpu", quantization_size=quantization_size))
+        out_s = network(create_input_batch(sbatch, True, device="cpu", quantization_size=quantization_size, coord_dtype=coord_dtype))
         loss_syn = criterion(out_s, sbatch["labels"])
         gw_syn = torch.autograd.grad(loss_syn, params, create_graph=True)
         m = match_loss(gw_syn, gw_real, dist_opt, "cpu", pyt)

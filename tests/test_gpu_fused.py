@@ -270,18 +270,33 @@ def test_fused_3d_point_clouds_vs_oracle(metric, shape):
     onet = R.MEConvExp(3, nclass, num_classes=nclass, dense_extent=ext)
     onet.load_state_dict(det_state_dict(onet, "net.3d"))
     onet = onet.double().train()
-    osyn = syn.clone().double().requires_grad_()
-    opt = torch.optim.SGD([osyn], lr=lr, momentum=0.5)   # small steps: the unclamped points must stay inside the dense extent
     for step in range(3):
+        # every step: the oracle starts from the device's fp32 points and quantises them as the reference does (the quotient point / voxel size
+        # taken in fp32, create_input_batch coord_dtype), so a point within rounding of a voxel face falls into the same voxel on both sides;
+        # everything after the integer coordinates is fp64.  The update is checked against lr * gradient (+ momentum) from the oracle.
+        osyn = fe.image_syn.detach().cpu().double().clone().requires_grad_()
         order = [rng.permutation(np.asarray(idx[c]))[:per] for c in range(nclass)]
         reals = [[clouds[i].double() for i in o] for o in order]
-        ref = R.matching_step(onet, osyn, reals, ipc, metric, False, optimizer=opt, num_points=npts, quantization_size=q)
+        ref = R.matching_step(onet, osyn, reals, ipc, metric, False, num_points=npts, quantization_size=q, coord_dtype=torch.float32)
+        before, mom = fe.image_syn.clone(), fe.momentum_buf.clone()
         le, lg = fe.outer_step(), fg.outer_step()
         assert lg.item() == le.item() and torch.equal(fg.image_syn, fe.image_syn), f"step {step}: graph != eager"
-        if step == 0:   # later steps: a synthetic point within rounding of a voxel face may quantise differently in fp32 and fp64
-            assert le.item() == pytest.approx(ref["loss"].item(), rel=1e-4)
-            assert rel_err(fe.last["grad"], ref["grad"]) < 1e-4
-            assert rel_err(fe.image_syn, osyn) < 1e-5
+        assert le.item() == pytest.approx(ref["loss"].item(), rel=1e-4), f"step {step}"
+        # a class whose gradient is off sits on a ReLU / arg-max discontinuity (fp32 and fp64 took different branches of a pooling window):
+        # at most one per step, and on the device's own branches it meets the tolerance (see _oracle_on_device_branches)
+        gref = ref["grad"].clone()
+        off = [c for c in range(nclass) if rel_err(fe.last["grad"][c * ipc:(c + 1) * ipc], gref[c * ipc:(c + 1) * ipc]) >= 1e-4]
+        assert len(off) <= 1, off
+        for c in off:
+            fr = _oracle_on_device_branches(fe, onet, osyn, reals, c, ipc, metric, num_points=npts, quantization_size=q, coord_dtype=torch.float32)
+            e_l, e_g = rel_err(fe.last["per_class"][c:c + 1], fr["per_class"]), rel_err(fe.last["grad"][c * ipc:(c + 1) * ipc], fr["grad"])
+            print(f"step {step}: class {c} on a discontinuity; replayed on the device's branches: loss rel {e_l:.2e}, xyz-grad {e_g:.2e}")
+            assert e_l < 1e-4 and e_g < 1e-4
+            assert rel_err(fe.last["per_class"][c:c + 1], ref["per_class"][c:c + 1]) < 1e-2
+            gref[c * ipc:(c + 1) * ipc] = fr["grad"]
+        assert rel_err(fe.last["grad"], gref) < 1e-4, f"step {step}"
+        want = before.cpu().double() - lr * (0.5 * mom.cpu().double() + gref)
+        assert rel_err(fe.image_syn, want) < 1e-5, f"step {step}"
     fg.check()
     assert fg._graph is not None and fg.row_counts()[0][0] > 3000
     from dd3d_amd.sparse import CloudCoordinateManager
@@ -354,7 +369,7 @@ def _discontinuity_classes(f, feats, tol=2e-6):
     return sorted({g % G for g in g0 | g1})
 
 
-def _oracle_on_device_branches(f, onet, osyn, reals, c, ipc, metric):
+def _oracle_on_device_branches(f, onet, osyn, reals, c, ipc, metric, **step_kw):
     """The fp64 oracle's step for class ``c`` alone, replayed on the branches the DEVICE took (oracle.minkowski_ref.forced_branches): the
     arg-max row of every pooled voxel and channel and whether its value passed the ReLU, read from the pass's own buffers (arg0 / arg1,
     P0 / P1 > 0), for the real and the synthetic batch of the class.  ReLU + max-pool restricted to a branch is linear, so on these branches
@@ -372,7 +387,7 @@ def _oracle_on_device_branches(f, onet, osyn, reals, c, ipc, metric):
         sets[g] = [(arg0, p.P0[b0:b1].cpu() > 0), (arg1, p.P1[c0:c1].cpu() > 0)]
     o = osyn.detach()[c * ipc:(c + 1) * ipc].clone().requires_grad_()
     with ME.forced_branches(sets[G + gi] + sets[gi]):
-        return R.matching_step(onet, o, [reals[gi]], ipc, metric, False, class_ids=[c])
+        return R.matching_step(onet, o, [reals[gi]], ipc, metric, False, class_ids=[c], **step_kw)
 
 
 def _graph_steps_vs_oracle(f, images, idx, rng, onet, ipc, per, metric, steps, tol=1e-4, replay=()):
@@ -504,6 +519,61 @@ def test_deferred_loss_mode_is_the_same_step_one_step_later(metric):
     assert fd2.flush().item() == prev
     fd.check()
     assert all(g is not None for g in fd._graphs)
+
+
+def test_cfg4_full_shape_step_properties():
+    """BASELINE configs[3] at FULL shape -- 40 classes x 256 real clouds x 1024 points in [-1,1]^3, voxel 0.05, ipc 10, dense extent 12^3,
+    10.9 M points and ~5 M voxel rows per step (k_cloud_emit<1024>, the second sort level of the launch schedule, the stream-K kernel
+    gradient with 80 groups) -- where the fp64 oracle would take hours.  Size-independent properties instead, over three steps:
+    the HIP-graph replay equals the eager step bit for bit (loss, points, gradient); every map the LDS builder made for the LAST step's
+    merged batch equals the global-hash builder's (coordinates at strides 1/2/4, cloud offsets, both kernel maps, both pooling maps,
+    inverse map); error flags stay zero; the loss is finite and the update moves every owned cloud and nothing else."""
+    from dd3d_amd.fused_step import FusedDistiller
+    from dd3d_amd.models.MEConv import MEConvExp
+    from dd3d_amd.sparse import CloudCoordinateManager, CoordinateManager
+    from dd3d_amd.synthetic import shell_clouds
+    nclass, per, ipc, npts = 40, 256, 10, 1024
+    clouds = shell_clouds(nclass * per, npts, seed=0)
+    idx = [list(range(c * per, (c + 1) * per)) for c in range(nclass)]
+    syn = (torch.rand((nclass * ipc, npts, 3), generator=torch.Generator().manual_seed(0)) * 1.8 - 0.9).float()
+
+    def net():
+        torch.manual_seed(0)
+        m = MEConvExp(3, nclass, num_classes=nclass, dense_extent=(12, 12, 12))
+        m.load_state_dict(det_state_dict(m, "net.cfg4"))
+        return m.to(DEV).train()
+
+    kw = dict(ipc=ipc, num_classes=nclass, num_points=npts, batch_size=per, device=DEV, seed=5, image_syn=syn, real_clouds=clouds,
+              quantization_size=0.05, clamp_range=(-0.95, 0.95), zero_first_axis=False, dist_lr=1e-6)
+    with FusedDistiller(None, idx, net(), graph=True, **kw) as fg, FusedDistiller(None, idx, net(), graph=False, **kw) as fe:
+        for step in range(3):
+            lg, le = fg.outer_step(), fe.outer_step()
+            assert lg.item() == le.item(), f"step {step}: graph {lg.item()} vs eager {le.item()}"
+            assert torch.equal(fg.image_syn, fe.image_syn) and torch.equal(fg.last["grad"], fe.last["grad"])
+            assert np.isfinite(lg.item())
+        fg.check()
+        fe.check()
+        assert fg._graph is not None
+        assert float((fg.image_syn - syn.to(DEV).clamp(-0.95, 0.95)).abs().amax(dim=(1, 2)).min()) > 0   # every cloud moved
+        M0, M1, M2 = fg.row_counts()[0]
+        assert M0 > 4_000_000 and M1 > 1_000_000
+        # the maps of the last replay against the global-hash chain on the same merged batch
+        st, cm = fg._static, fg.last["passes"][0].cm
+        assert isinstance(cm, CloudCoordinateManager)
+        N, B = int(st.n.item()), nclass * ipc + st.B
+        ref = CoordinateManager(st.coords[:N].clone(), B)
+        maps = [(1, 1, 3), (2, 2, 3), (1, 2, 2), (2, 4, 2)]
+        refmaps = [ref.kernel_map(*m) for m in maps]
+        ref.sync()
+        Ms = [ref.num_rows(s) for s in (1, 2, 4)]
+        assert Ms == [M0, M1, M2]
+        for s_, M in zip((1, 2, 4), Ms):
+            assert torch.equal(cm.levels[s_].C[:M], ref.coordinates(s_)), s_
+            assert torch.equal(cm.seg_off(s_), ref.seg_off(s_)), s_
+        assert torch.equal(cm.levels[1].inv[:N], ref.levels[1].inv[:N])
+        for m, (rm, _) in zip(maps, refmaps):
+            Mo = ref.num_rows(m[1])
+            assert torch.equal(cm.kernel_map(*m)[0][:, :Mo], rm[:, :Mo]), m
 
 
 def test_dropped_graph_distiller_is_torn_down_where_it_is_dropped():

@@ -457,6 +457,31 @@ def test_sparse_linear_bwd_w_layouts_groups_and_long_lists(B, J, gco):
     assert rel_err(outs["param"], ref) < 2e-5
 
 
+def test_true_divide_is_the_host_division_on_the_device():
+    """coordinates / quantization_size: the reference divides host tensors (a correctly rounded fp32 division, models/MEConv.py:262).  On the
+    device ``tensor / python_scalar`` multiplies by the rounded reciprocal -- different bits for a voxel size like 0.05, different VOXELS for
+    points at a face -- so the package divides through _lib.true_divide, which must give the host's bits; so must dd3d_gather_clouds."""
+    from dd3d_amd import _lib as L
+    g = torch.Generator().manual_seed(0)
+    x = (torch.rand(2_000_000, 3, generator=g) * 2 - 1).float()
+    faces = (torch.arange(-20, 21).float() * 0.05)[:, None].expand(-1, 3)            # points ON voxel faces and one ulp either side
+    x = torch.cat([x, faces, torch.nextafter(faces, torch.full_like(faces, 9.0)), torch.nextafter(faces, torch.full_like(faces, -9.0))]).contiguous()
+    for q in (0.05, 0.02, 1.0, 0.3):
+        want = x / q                                                                 # host division
+        assert torch.equal(L.true_divide(x.to(dev()), q).cpu(), want)
+        n = x.shape[0]
+        off = torch.tensor([0, n], dtype=torch.int32, device=dev())
+        ids = torch.zeros(1, dtype=torch.int32, device=dev())
+        coords, feats = torch.empty((n, 4), device=dev()), torch.empty((n, 3), device=dev())
+        pt_off, cnt, err = torch.zeros(2, dtype=torch.int32, device=dev()), torch.zeros(1, dtype=torch.int32, device=dev()), torch.zeros(1, dtype=torch.int32, device=dev())
+        L.call("dd3d_gather_clouds", L.ptr(x.to(dev())), L.ptr(off), 1, L.ptr(ids), 1, n, n, 0, 0, q, L.ptr(coords), L.ptr(feats), L.ptr(pt_off), L.ptr(cnt),
+               L.ptr(err), L.stream())
+        assert int(err.item()) == 0 and torch.equal(coords[:, 1:].cpu(), want) and torch.equal(feats.cpu(), x)
+    naive = (x.to(dev()) / 0.05).cpu()
+    print("tensor / 0.05 on the device differs from the host division in", int((naive != x / 0.05).sum()), "of", x.numel(), "elements;",
+          int((torch.floor(naive) != torch.floor(x / 0.05)).sum()), "land in another voxel")
+
+
 def test_dense_out_of_extent_is_an_error():
     from dd3d_amd.ops import DensePlacement
     coords = torch.tensor([[0, 0, 0.0, 0.0], [0, 0, 0.0, 200.0]])
