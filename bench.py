@@ -57,9 +57,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--ipc", type=int, default=IPC)
     ap.add_argument("--metric-name", default="modmse", help="dist_opt: modmse (INI default) | ours | mse | cos")
-    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4"],
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
                     help="BASELINE.json configs: cfg2 (default, the metric's configuration), cfg3 = cfg2 with 50 clouds/class, "
-                         "cfg4 = 40 classes x 256 real ellipsoid-shell clouds x 1024 pts, voxel 0.05, ipc 10 (record runs, not the headline)")
+                         "cfg4 = 40 classes x 256 real ellipsoid-shell clouds x 1024 pts, voxel 0.05, ipc 10; cfg5 = 55 classes x 256 x 2048 pts, voxel 0.02, "
+                         "dense extent 26^3, in chunks of --chunk classes in sequence (record runs, not the headline)")
+    ap.add_argument("--chunk", type=int, default=11, help="cfg5: classes per chunk (dd3d_amd.fused_step.ChunkedDistiller)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--emulate-shard", default="", help="R/W: time rank R's share of a W-rank job on this one GPU (no process group)")
     ap.add_argument("--real-split", default="off", help="second sharding level (graph / fused path): 'off' = classes only; 'auto' or P = the real batch "
@@ -101,7 +103,20 @@ def main():
     n_classes, n_points, extra = NUM_CLASSES, NUM_POINTS, {}
     if args.config == "cfg3":
         args.ipc = 50
-    if args.config == "cfg4":
+    if args.config == "cfg5":
+        from dd3d_amd.synthetic import shell_clouds
+        n_classes, n_points = 55, 2048
+        images_all = None
+        indices_class = [list(range(c * 320, (c + 1) * 320)) for c in range(n_classes)]
+        net = MEConvExp(in_channel=3, out_channel=n_classes, num_classes=n_classes, dense_extent=(26, 26, 26))
+        g = torch.Generator().manual_seed(0)
+        syn = (torch.rand((n_classes * args.ipc, n_points, 3), generator=g) * 1.8 - 0.9).float()
+        extra = dict(real_clouds=shell_clouds(n_classes * 320, n_points, seed=0), quantization_size=0.02, clamp_range=(-0.95, 0.95),
+                     zero_first_axis=False, dist_lr=1e-6)
+        args.no_cpu_baseline = True
+        if args.path == "graph":
+            args.path = "fused"   # chunks in sequence share the allocator's memory: eager launches (GPU-bound at this size)
+    elif args.config == "cfg4":
         from dd3d_amd.synthetic import shell_clouds
         n_classes, n_points = 40, 1024
         images_all = None
@@ -140,6 +155,9 @@ def main():
               seed=1234, image_syn=syn, classes=my_classes, **extra)
     if args.path == "dropin":
         d = Distiller(images_all, indices_class, net, **kw)
+    elif args.config == "cfg5":
+        from dd3d_amd.fused_step import ChunkedDistiller
+        d = ChunkedDistiller(images_all, indices_class, net, chunk=args.chunk, **kw)
     else:
         d = FusedDistiller(images_all, indices_class, net, graph=(args.path == "graph"), defer_loss=(args.path == "graph" and args.defer_loss), **kw,
                            **split_kw)
@@ -173,7 +191,9 @@ def main():
 
     def one_step(**kw):
         loss = d.outer_step(**kw)
-        if timer.on and args.path != "dropin":
+        if timer.on and hasattr(d, "pairs"):      # chunks of classes in sequence: one merged launch per chunk
+            pairs.extend(p1 for (_, p1) in d.pairs)
+        elif timer.on and args.path != "dropin":
             # pairs of the Cin=128 kernel maps of this step (a device->host read: only done in the kernel-timing region below)
             for i, (nbr, M, cnt) in enumerate(d.last["conv1_maps"]):
                 m = M if cnt is None else d.row_counts()[i][1]
@@ -185,6 +205,8 @@ def main():
         one_step()
     sync_all()
     timer.on = args.path != "graph"
+    if hasattr(d, "count_pairs"):
+        d.count_pairs = timer.on
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = one_step()
@@ -257,13 +279,18 @@ def main():
             # (the second-order pass over the synthetic prefix adds < 4 % and is left out)
             ps = d.last["passes"][0]
             M0, M1, M2 = d.row_counts()[0]
-            P0 = int((ps.maps[0][:, :M0] >= 0).sum().item())
-            P1 = int((ps.maps[4][:, :M1] >= 0).sum().item())
+            if hasattr(d, "pairs"):   # summed over the chunks of the last step
+                P0, P1 = sum(a for a, _ in d.pairs), sum(b for _, b in d.pairs)
+            else:
+                P0 = int((ps.maps[0][:, :M0] >= 0).sum().item())
+                P1 = int((ps.maps[4][:, :M1] >= 0).sum().item())
             ncls = len(d.classes)
             flop = 3 * (2.0 * P0 * 3 * 128 + 2.0 * P1 * 128 * 128 + 2.0 * M2 * 128 * n_classes)
             step_s = dt / args.steps
             # BASELINE.json's metric also asks for the achieved HBM GB/s of the bandwidth kernels: algorithmic bytes over the
             # same event timings, per kernel family, averaged over the eagerly enqueued steps
+            nch = len(d.chunks) if hasattr(d, "chunks") else 1   # launches per step of every kernel (chunks of about equal size)
+            m0, m1, m2, p0 = M0 / nch, M1 / nch, M2 / nch, P0 / nch
             fam = {}
             def add(key, t_ms, nbytes):
                 f = fam.setdefault(key, [0.0, 0.0])
@@ -272,16 +299,16 @@ def main():
             lv = 0
             for (n, t, a) in rec:
                 if n in ("dd3d_inorm_arp_fwd", "dd3d_inorm_arp_fwd_y"):
-                    mi, mo = ((M0, M1), (M1, M2))[lv % 2]
+                    mi, mo = ((m0, m1), (m1, m2))[lv % 2]
                     # Y read (+ xhat written by the stored-xhat launch), pooled + arg written
                     add("instance norm + affine + ReLU + max-pool forward (k_inorm_arp_fwd)", t, (512.0 if n.endswith("_y") else 1024.0) * mi + 1024.0 * mo)
                     lv += 1
                 elif n == "dd3d_conv_fwd" and a[2] == 3:
-                    add("first-layer convolution forward (k_conv3_fwd)", t, 4.0 * (3 * M0 + 128 * M0) + 8.0 * P0 + 4 * 27 * 3 * 128)
+                    add("first-layer convolution forward (k_conv3_fwd)", t, 4.0 * (3 * m0 + 128 * m0) + 8.0 * p0 + 4 * 27 * 3 * 128)
             lv = 0
             for (n, t, a) in rec:
                 if n in ("dd3d_arp_inorm_bwd", "dd3d_arp_inorm_bwd_y"):
-                    mi, mo = ((M1, M2), (M0, M1))[lv % 2]
+                    mi, mo = ((m1, m2), (m0, m1))[lv % 2]
                     add("pool + ReLU + affine + instance norm backward (k_arp_inorm_bwd)", t, 1024.0 * mi + 1024.0 * mo)
                     lv += 1
             hbm = {k: {"GB_per_s": v[1] / (v[0] * 1e-3) / 1e9, "frac_of_8TBps": v[1] / (v[0] * 1e-3) / 8e12} for k, v in fam.items() if v[0] > 0}
@@ -290,14 +317,18 @@ def main():
         out = {"metric": METRIC, "value": args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
                "data": "synthetic", "config": {"workload": (f"{args.config}: MNIST-3D-shaped stroke digits, {NUM_CLASSES} classes x {REAL_PER_CLASS} real clouds, "
-                                                            f"ipc={args.ipc} x {NUM_POINTS} pts, MEConvExp, dist_opt={args.metric_name}") if args.config != "cfg4" else
+                                                            f"ipc={args.ipc} x {NUM_POINTS} pts, MEConvExp, dist_opt={args.metric_name}") if args.config not in ("cfg4", "cfg5") else
                                                            (f"cfg4: ModelNet40-shaped ellipsoid shells, 40 classes x {REAL_PER_CLASS} real clouds x 1024 pts, voxel 0.05, "
-                                                            f"ipc={args.ipc}, MEConvExp(num_classes=40, dense_extent=12^3), dist_opt={args.metric_name}"),
+                                                            f"ipc={args.ipc}, MEConvExp(num_classes=40, dense_extent=12^3), dist_opt={args.metric_name}") if args.config == "cfg4" else
+                                                           (f"cfg5: ShapeNet-shaped ellipsoid shells, 55 classes x {REAL_PER_CLASS} real clouds x 2048 pts, voxel 0.02, ipc={args.ipc}, "
+                                                            f"MEConvExp(num_classes=55, dense_extent=26^3), dist_opt={args.metric_name}; chunks of {args.chunk} classes in sequence"),
                                                "loss_all_reduce": ("per step" if args.reduce_loss == "step" else "once, after the last timed step (inside the timed region)") if world > 1 else None,
                                                "parallelism": f"class-sharded x{world}" + (f", real batches split x{split_kw['real_part'][1]}" if split_kw else ""),
                                                "path": {"graph": "class-batched step, one HIP graph replay per step", "fused": "class-batched step, eager launches",
                                                         "dropin": "drop-in autograd loop"}[args.path]},
                "loss": loss_value, "roofline": roof, "step_work": step_work, "hbm": hbm if args.path != "dropin" else None}
+        if args.config in ("cfg4", "cfg5"):
+            out["peak_hbm_GB"] = torch.cuda.max_memory_allocated() / 1e9
         if not args.no_cpu_baseline and world == 1:
             # the reference-shaped loop (the Distiller of dd3d_amd/mnist_distill.py: per-class autograd, what "loop body unchanged" means in
             # INTEGRATION.md) on the same workload, 3 steps after 1 warm-up, beside the class-batched graph step that `value` reports

@@ -234,9 +234,6 @@ __global__ __launch_bounds__(256) void k_split_sum(const f32x4* __restrict__ par
 // the 16 KB weight chunk of a step is shared, double-buffered in LDS: ONE barrier per step, and the loads of step s+1 (A into the
 // other register set, W into staging registers) are in flight under the 64 MFMAs of step s.  The k-index assignment and the
 // order of the accumulation are those of k_conv128, so the two kernels give bit-identical results.
-#ifndef DD3D_EXP
-#define DD3D_EXP 0
-#endif
 #ifdef DD3D_CONV_PROF  // `make prof`: wave 0..3 of the first 1024 workgroups leave timestamps (100 MHz wall clock) and their placement
 __device__ long long g_prof[1024 * 4 * 8];
 #define PROF_T(x) const long long x = wall_clock64()
@@ -358,11 +355,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv128_rows(const float* __restric
         }
         const bool more = nk >= 0;
         if (!more) nk = k, nkc = kc;
-#if DD3D_EXP == 3
-        const f32x4* pa = X4 + (int64_t)((nk * 977 + tile * 32 + i32) % M_out) * 32 + nkc * 8 + h * 4;
-#else
         const f32x4* pa = X4 + (int64_t)max(nbn, 0) * 32 + nkc * 8 + h * 4;
-#endif
         const f32x4* pw = W4 + ((int64_t)nk * 128 + nkc * 32) * 32 + tid;
         PROF_T(q1);
         {
@@ -373,18 +366,11 @@ __global__ __launch_bounds__(NW * 64) void k_conv128_rows(const float* __restric
             for (int s = 0; s < 16; s += 2) {
                 f32x4 n0 = b0, n1 = b1;
                 if (s + 2 < 16) n0 = Bp[(s + 2) * 32], n1 = Bp[(s + 3) * 32];
-#if DD3D_EXP != 1
                 if (s == 0) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) nxt[j] = pa[j];
                 }
-#else
-                if (s == 0) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) nxt[j] = cur[j];
-                }
-#endif
-                if (DD3D_EXP != 2 && s < 4) {  // all of the prefetch is out after the first quarter of the step: a microsecond before it is needed
+                if (s < 4) {  // all of the prefetch is out after the first quarter of the step: a microsecond before it is needed
 #pragma unroll
                     for (int j = s / 2 * ((BPT + 1) / 2); j < (s / 2 + 1) * ((BPT + 1) / 2) && j < BPT; ++j) rb[j] = pw[j * NTH];
                 }

@@ -1136,6 +1136,20 @@ class FusedDistiller:
         if self._closed:
             raise RuntimeError("this FusedDistiller was closed")
         self._apply_update = apply_update
+        # The side streams take the priority of the stream the step is launched on: a step launched on a high-priority stream whose side
+        # streams had the default priority never finished (measured on ROCm 7.2: the launching stream waits for its side streams' events
+        # while its own queue outranks theirs)
+        prio = getattr(torch.cuda.current_stream(self.device), "priority", 0)
+        if prio != 0 and self.use_graph:
+            # (eager steps run there once the side streams share the priority; the REPLAY of the captured graph did not return: the
+            # runtime's own graph streams keep the default priority)
+            raise RuntimeError("graph mode needs a stream of default priority: a HIP-graph replay launched on a high-priority stream hangs on ROCm 7.2 "
+                               "(use graph=False on such a stream)")
+        if prio != getattr(self.stream_side, "priority", 0):
+            if self.steps_done > 0:
+                raise RuntimeError("this FusedDistiller has taken steps on a stream of another priority; use one stream priority per distiller")
+            self.stream_side, self.stream_side2, self.stream_data = (torch.cuda.Stream(self.device, priority=prio) for _ in range(3))
+            self.stream_defer = self.stream_side2
         if self.use_graph and real_batch is None and apply_update:
             if self._static is None:
                 self._build_static()
@@ -1188,3 +1202,52 @@ class FusedDistiller:
             with torch.cuda.stream(self.stream_data):
                 self._prefetched = self.sample_real()
         return total
+
+
+class ChunkedDistiller:
+    """The matching step over CHUNKS of classes in sequence on one device: one FusedDistiller per chunk, all of them updating their own
+    rows of ONE synthetic-point tensor (and momentum buffer).  The classes are independent inside a step (mnist_distill.py:335), so
+    this is the class-sharding mechanism of dd3d_amd/sharding.py run in sequence; it is what a configuration needs whose per-group
+    gradient lists do not fit beside each other (BASELINE configs[4]: 55 classes, a 2.25 M-column classifier -- 54 GB of classifier
+    gradients for all 110 groups at once).  Eager launches: the chunks reuse one another's memory through the allocator, and kernels of
+    this size are GPU-bound anyway.  Same results as one FusedDistiller over all classes (tests/test_gpu_fused.py)."""
+
+    def __init__(self, images_all, indices_class, network, ipc, num_classes, chunk, classes=None, image_syn=None, **kw):
+        kw.pop("graph", None)
+        self.classes = list(range(num_classes)) if classes is None else list(classes)
+        self.chunks = [self.classes[a:a + chunk] for a in range(0, len(self.classes), chunk)]
+        self.parts = []
+        for ch in self.chunks:
+            d = FusedDistiller(images_all, indices_class, network, ipc, num_classes=num_classes, classes=ch, image_syn=image_syn, graph=False, **kw)
+            if self.parts:   # every chunk works on the first one's tensors
+                d.image_syn, d.momentum_buf = self.parts[0].image_syn, self.parts[0].momentum_buf
+            self.parts.append(d)
+        self.image_syn, self.momentum_buf = self.parts[0].image_syn, self.parts[0].momentum_buf
+        self.defer, self.use_graph, self.last, self._rows = False, False, {}, []
+        self.count_pairs, self.pairs = False, []   # (measurement) pairs of both kernel maps of every chunk of the last step
+
+    def outer_step(self, **kw):
+        kw.pop("force_eager", None)
+        total, self._rows, self.pairs = None, [], []
+        for d in self.parts:
+            loss = d.outer_step(**kw)
+            total = loss if total is None else total + loss
+            self._rows.append(d.row_counts()[0])
+            if self.count_pairs:
+                ps, (M0, M1, _) = d.last["passes"][0], self._rows[-1]
+                self.pairs.append((int((ps.maps[0][:, :M0] >= 0).sum().item()), int((ps.maps[4][:, :M1] >= 0).sum().item())))
+            self.last = d.last
+            if d is not self.parts[-1]:
+                d.last = {}       # the chunk's gradient lists go back to the allocator before the next chunk runs
+        return total
+
+    def row_counts(self):
+        """((M0, M1, M2),) summed over the chunks of the last step."""
+        return (tuple(sum(r[i] for r in self._rows) for i in range(3)),)
+
+    def check(self):
+        self.parts[-1].check()
+
+    def close(self):
+        for d in self.parts:
+            d.close()
