@@ -706,6 +706,7 @@ __global__ void k_sgd_scatter(float* __restrict__ x, float* __restrict__ mom, co
     for (int a = 0; a < 3; ++a) {
         const float g = d >= 0 ? dfeats[r * 3 + a] : 0.f;
         if (grad_out) grad_out[p * 3 + a] = g;
+        if (d < 0) continue;  // another owner's cloud (another rank, another chunk of classes): neither moved nor its momentum touched
         const float m = momentum * mom[p * 3 + a] + g;
         mom[p * 3 + a] = m;
         x[p * 3 + a] = x[p * 3 + a] - lr * m;

@@ -641,6 +641,7 @@ class FusedDistiller:
         self._graph = self._static = None
         self._graph_stamp, self._needs_eager, self._last_loss = None, False, None
         self._scope = "graph%x" % id(self)
+        self.prefetch = True   # eager mode: sample the next step's real batch right behind this step (ChunkedDistiller: off, the chunks share one sample stream)
         self.so_early = os.environ.get("DD3D_SO_EARLY", "1") != "0"   # second-order pass started next to the first-order tail (_compute_gen)
         self._counters = _group_counters(dev, G + self.Gr)   # this distiller's own (its graphs keep the address)
         self._closed = False
@@ -1198,7 +1199,7 @@ class FusedDistiller:
         total = self._compute(self._merge_eager(rb, xyz), False)
         if apply_update:
             self.steps_done += 1
-        if real_batch is None and not self.use_graph:
+        if real_batch is None and not self.use_graph and self.prefetch:
             with torch.cuda.stream(self.stream_data):
                 self._prefetched = self.sample_real()
         return total
@@ -1210,7 +1211,8 @@ class ChunkedDistiller:
     this is the class-sharding mechanism of dd3d_amd/sharding.py run in sequence; it is what a configuration needs whose per-group
     gradient lists do not fit beside each other (BASELINE configs[4]: 55 classes, a 2.25 M-column classifier -- 54 GB of classifier
     gradients for all 110 groups at once).  Eager launches: the chunks reuse one another's memory through the allocator, and kernels of
-    this size are GPU-bound anyway.  Same results as one FusedDistiller over all classes (tests/test_gpu_fused.py)."""
+    this size are GPU-bound anyway.  Same results as one FusedDistiller over all classes (tests/test_gpu_fused.py); a chunk's clamp also goes
+    over the clouds the chunks before it have just moved -- the clamp the next step applies to them anyway."""
 
     def __init__(self, images_all, indices_class, network, ipc, num_classes, chunk, classes=None, image_syn=None, **kw):
         kw.pop("graph", None)
@@ -1219,8 +1221,9 @@ class ChunkedDistiller:
         self.parts = []
         for ch in self.chunks:
             d = FusedDistiller(images_all, indices_class, network, ipc, num_classes=num_classes, classes=ch, image_syn=image_syn, graph=False, **kw)
-            if self.parts:   # every chunk works on the first one's tensors
-                d.image_syn, d.momentum_buf = self.parts[0].image_syn, self.parts[0].momentum_buf
+            if self.parts:   # every chunk works on the first one's tensors and draws from its sample stream (class after class, as one batch would)
+                d.image_syn, d.momentum_buf, d.rng = self.parts[0].image_syn, self.parts[0].momentum_buf, self.parts[0].rng
+            d.prefetch = False
             self.parts.append(d)
         self.image_syn, self.momentum_buf = self.parts[0].image_syn, self.parts[0].momentum_buf
         self.defer, self.use_graph, self.last, self._rows = False, False, {}, []

@@ -271,7 +271,11 @@ int dd3d_arp_inorm_bwd_y(const float* g_pool, const int32_t* arg, const int32_t*
  * ends; its device address is taken once per device with hipGetSymbolAddress.  B > dd3d_arp_inorm_bwd_static_max_clouds() (8192)
  * returns -2 (use dd3d_arp_inorm_bwd with a caller workspace there).  Same kernels, same outputs bit for bit.  All calls on one GPU
  * share that GPU's array: calls that overlap on one GPU (two streams, two threads) race -- serialise them.  Nothing needs clearing
- * between calls: every slot a call reads, it has written. */
+ * between calls: every slot a call reads, it has written.
+ * Set-up: the FIRST call on a device takes the array's address (hipGetDevice + hipGetSymbolAddress, host-side queries).  A caller that
+ * will make its calls under graph capture makes one call OUTSIDE capture first, with that device current -- B = 0 (w, b non-null,
+ * everything else may be null) launches nothing and returns 0 with the address taken (tests/test_zz_no_alloc.py captures the call
+ * after exactly this set-up, in a fresh process). */
 int dd3d_arp_inorm_bwd_static_max_clouds(void);
 int dd3d_arp_inorm_bwd_static(const float* g_pool, const int32_t* arg, const int32_t* parent, const float* xhat, const float* inv_std,
                               const float* w, const float* b, int C, const int32_t* seg_off, int B, const int32_t* cloud_group,

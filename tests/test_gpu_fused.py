@@ -576,6 +576,34 @@ def test_cfg4_full_shape_step_properties():
             assert torch.equal(cm.kernel_map(*m)[0][:, :Mo], rm[:, :Mo]), m
 
 
+def test_chunked_distiller_equals_one_batch():
+    """ChunkedDistiller (class chunks in sequence on one device, what bench.py runs for BASELINE configs[4]) against one FusedDistiller over
+    all classes: the classes are independent inside a step, so losses, gradients and updated points agree to fp32 rounding (the row-chunk /
+    stream-K partitions of the kernel gradients follow the batch, so not bit for bit) over three steps; every chunk updates its own rows
+    of the one synthetic tensor."""
+    from dd3d_amd.fused_step import ChunkedDistiller, FusedDistiller
+    from dd3d_amd.synthetic import mnist3d_like
+    images, _, idx = mnist3d_like(5, 40, seed=3)
+    syn = init_synthetic(5, 3, 250, seed=1)
+    kw = dict(ipc=3, num_classes=5, batch_size=24, dist_opt="ours", device=DEV, seed=11, image_syn=syn)
+    one = FusedDistiller(images, idx, _net(), graph=False, **kw)
+    ch = ChunkedDistiller(images, idx, _net(), chunk=2, **kw)
+    assert [len(c) for c in ch.chunks] == [2, 2, 1] and all(d.image_syn is ch.image_syn for d in ch.parts)
+    for step in range(3):
+        l1, lc = one.outer_step(), ch.outer_step()
+        assert rel_err(lc.reshape(1), l1.reshape(1)) < 1e-5
+        # (a later chunk's clamp -- the one the NEXT step applies to every cloud anyway, mnist_distill.py:311-317 -- has already gone over the
+        # clouds the earlier chunks moved: compare the points as the next step will see them)
+        a, b = ch.image_syn.clone().clamp_(0, 27), one.image_syn.clone().clamp_(0, 27)
+        a[:, :, 0], b[:, :, 0] = 0, 0
+        assert rel_err(a, b) < 1e-6
+        assert rel_err(ch.parts[0].momentum_buf, one.momentum_buf) < 1e-5
+        assert ch.row_counts()[0] == one.row_counts()[0]
+    ch.check()
+    ch.close()
+    one.close()
+
+
 def test_dropped_graph_distiller_is_torn_down_where_it_is_dropped():
     """Teardown of a distiller with captured graphs: it sits in no reference cycle, so dropping the last reference frees it THERE (not in
     some later pass of the cyclic collector), and close() -- which __del__ calls -- waits for the distiller's streams before the graphs

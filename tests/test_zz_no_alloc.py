@@ -70,3 +70,41 @@ def test_no_alloc_entry_point_equals_workspace_entry_point():
     assert mx == 8192
     rc = L.lib.dd3d_arp_inorm_bwd_static(*([None] * 7), 128, None, mx + 1, None, None, 1, None, None, 0, None, None, None, None, None)
     assert rc == -2
+
+
+_CAPTURE_CHILD = r"""
+import sys, torch
+sys.path.insert(0, {root!r})
+from tests.test_zz_no_alloc import _case, _run, DEV
+from dd3d_amd import _lib as L
+B, G = 40, 3
+t, M_in = _case(B, G, 60, 5)
+w1 = torch.ones(1, device=DEV)
+# set-up call OUTSIDE capture: B = 0 launches nothing and takes the array's address on this device (include/dd3d.h)
+assert L.lib.dd3d_arp_inorm_bwd_static(None, None, None, None, None, L.ptr(w1), L.ptr(w1), 128, None, 0, None, None, 1, None, None, 0, None, None, None, None, L.stream()) == 0
+dY, ga = torch.full((M_in, 128), 7.0, device=DEV), torch.full((M_in, 128), 7.0, device=DEV)
+gw_w, gw_b = torch.full((G, 128), 7.0, device=DEV), torch.full((G, 128), 7.0, device=DEV)
+free0 = torch.cuda.mem_get_info()[0]
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    L.call("dd3d_arp_inorm_bwd_static", L.ptr(t["g_pool"]), L.ptr(t["arg"]), L.ptr(t["parent"]), L.ptr(t["xhat"]), L.ptr(t["inv_std"]), L.ptr(t["w"]), L.ptr(t["b"]),
+           128, L.ptr(t["seg"]), B, L.ptr(t["cg"]), L.ptr(t["gco"]), G, L.ptr(dY), L.ptr(ga), B // 2, None, None, L.ptr(gw_w), L.ptr(gw_b), L.stream())
+g.replay()
+torch.cuda.synchronize()
+want = _run(False, t, M_in, B, G, False)
+for a, b in zip((dY, ga, gw_w, gw_b), want):
+    assert torch.equal(a, b)
+print("captured-ok")
+"""
+
+
+def test_no_alloc_entry_point_under_graph_capture_after_a_set_up_call():
+    """The entry point is meant for callers under HIP-graph capture: in a FRESH process, one set-up call outside capture (B = 0: nothing is
+    launched, the device address of the static array is taken), then the real call captured into a graph and replayed; outputs
+    bit-identical to the workspace entry point."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _CAPTURE_CHILD.format(root=root)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "captured-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
