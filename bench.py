@@ -268,10 +268,21 @@ def main():
         # HBM bytes per launch of this kernel: PMC counters cannot be read from inside the process, so the figure comes from the
         # committed rocprofv3 --pmc passes of this same command (tools/pmc.sh -> tools/pmc_to_json.py), corrected as the file says;
         # only attached to the run it was measured on (one GPU, all classes, default ipc)
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_conv128_rows.json")
+        pmc = os.path.join(ROOT, "profiles", "r03_pmc_conv128_rows.json")
+        trace = os.path.join(ROOT, "profiles", "r03_graph_step_kernel_stats.csv")
         if args.path != "dropin" and args.config == "cfg2" and args.ipc == IPC and world == 1 and not args.emulate_shard and tile_rows == 128 and os.path.exists(pmc):
             roof["traffic"] = json.load(open(pmc))["traffic_bytes_per_launch"]
-            roof["traffic_source"] = "profiles/r02_pmc_conv128_rows.json (rocprofv3 --pmc passes of this command, not this run)"
+            roof["traffic_source"] = "profiles/r03_pmc_conv128_rows.json (rocprofv3 --pmc passes of this command, not this run)"
+            if os.path.exists(trace):
+                # the same kernel INSIDE the replayed graph (next to the side streams' kernels): average duration over every launch of the
+                # committed rocprofv3 --kernel-trace --stats run of this command, beside the eager-timed figure above
+                import csv
+                for r in csv.DictReader(open(trace)):
+                    if "k_conv128_rows" in r["Name"]:
+                        us = float(r["AverageNs"]) / 1e3
+                        roof["in_graph_trace"] = {"avg_launch_us": us, "achieved": avg_flop / (us * 1e-6) / 1e12, "frac": avg_flop / (us * 1e-6) / 1e12 / 157.3,
+                                                  "calls": int(r["Calls"]), "source": "profiles/r03_graph_step_kernel_stats.csv (not this run)"}
+                        break
         step_work = None
         if args.path != "dropin":
             # the counts the algorithmic work of a step follows from (merged batch of the last step of this rank) and the

@@ -28,7 +28,10 @@ __host__ __device__ __forceinline__ int chunk3(int M) {
 }
 __host__ __device__ __forceinline__ int chunk128(int M) {
     int ch = (((M > 0 ? M : 1) + 255) / 256 + 31) / 32 * 32;
-    const int lo = M >= 65536 ? 512 : 128;  // small launches (a synthetic batch, one class per GPU) need many short chunks to fill the CUs
+#ifndef DD3D_CHUNK128_MIN
+#define DD3D_CHUNK128_MIN 512
+#endif
+    const int lo = M >= 65536 ? DD3D_CHUNK128_MIN : 128;  // small launches (a synthetic batch, one class per GPU) need many short chunks to fill the CUs
     return ch < lo ? lo : ch;
 }
 // slots needed for ANY row count <= bound: the chunk size is smallest (64 / 512) when there are few rows
