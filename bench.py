@@ -248,7 +248,10 @@ def main():
         Mf = max([c[0] for c in conv], default=0)
         conv = [c for c in conv if c[0] == Mf]
         fwd, mir = [c[2] for c in conv if not c[1]], [c[2] for c in conv if c[1]]
-        ms = fwd + mir
+        # The roofline figure is the FORWARD launch: it runs alone on the GPU, eagerly and inside the replayed graph alike (k_conv128_rows<4, 0> in
+        # a kernel trace).  The mirrored = backward-data launch (k_conv128_rows<4, 1>, same rows and pairs) shares the matrix pipe with the
+        # 128-channel kernel gradient inside the graph on purpose; its durations are reported beside it.
+        ms = fwd if fwd else mir
         pairs += [int((nbr[:, :M] >= 0).sum().item()) for (nbr, M) in nbr_keep]
         avg_pairs = sum(pairs) / max(len(pairs), 1)
         avg_ms = sum(ms) / max(len(ms), 1)
@@ -256,14 +259,14 @@ def main():
         mean = lambda v: sum(v) / max(len(v), 1)
         scheduled = any(c[3] for c in conv)
         tile_rows = 128 if Mf >= BIG else 32
-        kname = ("k_conv128_rows<4>" if tile_rows == 128 else "k_conv128<32,1,4>") + (
-            " (Cin=Cout=128 convolution on the merged batch, forward and mirrored = backward-data launches, " +
+        kname = ("k_conv128_rows<4, 0>" if tile_rows == 128 else "k_conv128<32,1,4>") + (
+            " (Cin=Cout=128 convolution on the merged batch, forward launch; the mirrored = backward-data launch is listed beside it, " +
             ("scheduled launch dd3d_conv128_ordered" if scheduled else "plain launch dd3d_conv_fwd") + ", fp32 MFMA 32x32x2)")
         roof = {"bound": "mfma", "kernel": kname, "achieved": avg_flop / (avg_ms * 1e-3) / 1e12 if ms else None,
                 "peak": 157.3, "unit": "TFLOP/s", "traffic": None, "traffic_measured_in_run": False, "launches": len(ms), "avg_launch_us": avg_ms * 1e3,
                 "avg_launch_us_forward": mean(fwd) * 1e3, "avg_launch_us_mirrored": mean(mir) * 1e3, "avg_pairs_per_launch": avg_pairs,
-                "timing": "HIP events on the launching stream around every launch of the kernel, over the steps enqueued eagerly after the timed "
-                          "graph replays (identical kernels, arguments and launch bounds); both launches of a step count"}
+                "timing": "HIP events on the launching stream around every forward launch of the kernel, over the steps enqueued eagerly after the timed "
+                          "graph replays (identical kernels, arguments and launch bounds)"}
         roof["frac"] = roof["achieved"] / roof["peak"] if ms else None
         # HBM bytes per launch of this kernel: PMC counters cannot be read from inside the process, so the figure comes from the
         # committed rocprofv3 --pmc passes of this same command (tools/pmc.sh -> tools/pmc_to_json.py), corrected as the file says;
@@ -278,11 +281,11 @@ def main():
                 # committed rocprofv3 --kernel-trace --stats run of this command, beside the eager-timed figure above
                 import csv
                 for r in csv.DictReader(open(trace)):
-                    if "k_conv128_rows" in r["Name"]:
-                        us = float(r["AverageNs"]) / 1e3
-                        roof["in_graph_trace"] = {"avg_launch_us": us, "achieved": avg_flop / (us * 1e-6) / 1e12, "frac": avg_flop / (us * 1e-6) / 1e12 / 157.3,
-                                                  "calls": int(r["Calls"]), "source": "profiles/r03_graph_step_kernel_stats.csv (not this run)"}
-                        break
+                    for tag, key in (("k_conv128_rows<4, 0>", "in_graph_trace"), ("k_conv128_rows<4, 1>", "in_graph_trace_mirrored")):
+                        if tag in r["Name"]:
+                            us = float(r["AverageNs"]) / 1e3
+                            roof[key] = {"avg_launch_us": us, "achieved": avg_flop / (us * 1e-6) / 1e12, "frac": avg_flop / (us * 1e-6) / 1e12 / 157.3,
+                                         "calls": int(r["Calls"]), "source": "profiles/r03_graph_step_kernel_stats.csv (not this run)"}
         step_work = None
         if args.path != "dropin":
             # the counts the algorithmic work of a step follows from (merged batch of the last step of this rank) and the

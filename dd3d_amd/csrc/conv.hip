@@ -245,7 +245,9 @@ __device__ long long g_prof[1024 * 4 * 8];
 #define PROF_T(x)
 #define PROF_ADD(acc, a, b)
 #endif
-template <int NW>
+// MIRRORED only tags the instantiation (the mirrored = backward-data launch of a step runs beside the kernel gradient on purpose, the
+// forward launch alone: two symbols keep their durations apart in a kernel trace); the code is the same, `mirror` stays a runtime argument.
+template <int NW, int MIRRORED = 0>
 __global__ __launch_bounds__(NW * 64) void k_conv128_rows(const float* __restrict__ X, const float* __restrict__ W, const int* __restrict__ nbr, int64_t ld,
                                                           int K, int M_bound, const int* __restrict__ m_dev, int mirror, float* __restrict__ Y, int xcd_remap,
                                                           const int* __restrict__ perm, const int* __restrict__ tile_map,
@@ -1047,8 +1049,12 @@ DD3D_API int dd3d_conv_fwd(const float* X, int64_t M_in, int Cin, const float* W
         const bool big = dbg_tile ? dbg_tile == 128 : M_out >= 128 * 512;
         if (big && dbg_rows) {
             const int64_t nt = ceil_div64(M_out, 128);
-            k_conv128_rows<4><<<dim3((unsigned)(ceil_div64(nt, 8) * 8)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, dbg_xcd, nullptr, nullptr,
-                                                                                      nullptr, nullptr);
+            if (mirror)
+                k_conv128_rows<4, 1><<<dim3((unsigned)(ceil_div64(nt, 8) * 8)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, dbg_xcd, nullptr, nullptr,
+                                                                                             nullptr, nullptr);
+            else
+                k_conv128_rows<4, 0><<<dim3((unsigned)(ceil_div64(nt, 8) * 8)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, dbg_xcd, nullptr, nullptr,
+                                                                                             nullptr, nullptr);
         } else if (big) {
             const int64_t nt = ceil_div64(M_out, 128);
             k_conv128<128, 2, 2><<<dim3((unsigned)(ceil_div64(nt, 8) * 8)), 256, 0, st>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, dbg_xcd);
@@ -1078,8 +1084,10 @@ DD3D_API int dd3d_conv128_ordered(const float* X, int64_t M_in, const float* W, 
     if (M_out == 0) return 0;
     if (!X || !W || !nbr || !Y || !perm || !tile_map || (nbr_sorted == nullptr) != (tile_mask == nullptr)) return DD3D_EARG;
     const unsigned nb = (unsigned)dd3d_conv_schedule_blocks(M_out);
-    if (dd3d_conv_schedule_tile_rows(M_out) == 128)
-        k_conv128_rows<4><<<dim3(nb), 256, 0, (hipStream_t)stream>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, 0, perm, tile_map, nbr_sorted, tile_mask);
+    if (dd3d_conv_schedule_tile_rows(M_out) == 128 && mirror)
+        k_conv128_rows<4, 1><<<dim3(nb), 256, 0, (hipStream_t)stream>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, 0, perm, tile_map, nbr_sorted, tile_mask);
+    else if (dd3d_conv_schedule_tile_rows(M_out) == 128)
+        k_conv128_rows<4, 0><<<dim3(nb), 256, 0, (hipStream_t)stream>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, 0, perm, tile_map, nbr_sorted, tile_mask);
     else  // small launches: 32-row tiles (see dd3d_conv_fwd), same schedule machinery
         k_conv128<32, 1, 4><<<dim3(nb), 256, 0, (hipStream_t)stream>>>(X, W, nbr, ld, K, (int)M_out, m_dev, mirror, Y, 0, perm, tile_map);
     DD3D_CHECK_LAUNCH();

@@ -43,9 +43,26 @@ def _empty(shape, dev, dtype=_F32):
     return torch.empty(shape, dtype=dtype, device=dev)
 
 
-def conv_kernel_gradient(X, Cin, dY, nbr, ld, M, gro, G, dev, seg=None, B=0, err=None):
-    """dW [G, 27, Cin, 128] of a stride-1 convolution on the current stream (one kernel gradient per group of rows)."""
-    dW = _empty((G, 27, Cin, 128), dev)
+def _same(a, b):
+    return a.cuda_stream == b.cuda_stream
+
+
+def _wait(a, b):
+    """Stream ``a`` waits for everything enqueued on ``b`` so far.  Nothing to do on one and the same stream -- a pass may run with its
+    side streams set to its own stream (the pipelined step's synthetic pass), and a stream waiting for its own event inside a capture
+    crashed hipStreamEndCapture on ROCm 7.2."""
+    if not _same(a, b):
+        a.wait_stream(b)
+
+
+def _wait_event(a, ev, recorded_on):
+    if not _same(a, recorded_on):
+        a.wait_event(ev)
+
+
+def conv_kernel_gradient(X, Cin, dY, nbr, ld, M, gro, G, dev, seg=None, B=0, err=None, out=None):
+    """dW [G, 27, Cin, 128] of a stride-1 convolution on the current stream (one kernel gradient per group of rows); ``out``: a caller's buffer."""
+    dW = out if out is not None else _empty((G, 27, Cin, 128), dev)
     if Cin == 128 and seg is not None and os.environ.get("DD3D_BWW_CLOUDS", "0") != "0":
         # small clouds: whole-cloud windows of both operands in LDS (conv_bww.hip).  Off by default: alone it takes what the row-chunk kernel
         # and its slab sum take (243 + 10 us against 223 + 30 us at cfg2, with a quarter of the memory traffic), but its workgroups fill a
@@ -130,12 +147,15 @@ class _Pass:
             gro1, gro2 = seg1[gidx].contiguous(), seg2[gidx].contiguous()   # rows of every group at tensor strides 1 and 2
         self._pre = (k0, p0, k1, p1, seg1, seg2, gro1, gro2)
 
-    def run(self, feats, labels, defer=False, early=None):
+    def run(self, feats, labels, defer=False, early=None, gw_out=None):
         """Phase 2: (eager mode: ONE device->host read of the row counts, then) forward + first-order backward on the current stream.
         ``early(pass, ev_l2)`` (optional): called once the input gradient of the 128-channel convolution is in the main stream's queue;
         by then the side stream holds the classifier's gradients and the main stream has produced the second level's (event ``ev_l2``),
         i.e. three of the four differentiable entries of gw exist.  FusedDistiller uses it to start the matching loss over them and the
         second-order pass on the side stream, next to the rest of the first-order backward.
+        ``gw_out`` (optional): eight caller-owned tensors [G, *parameter shape] (order of network.parameters(), the classifier weight in the
+        step's layout) that receive the gradient lists -- buffers that outlive the pass (the pipelined step hands a real pass's lists to
+        the NEXT step's synthetic pass).
         ``defer`` (needs a stash): the two kernel gradients of the convolutions, which feed nothing but the loss VALUE, are not launched here;
         their operands are written into the stash, and FusedDistiller runs them next to the beginning of the following step."""
         stash = self.stash
@@ -199,7 +219,7 @@ class _Pass:
         if use_sched:
             # the 128-row kernel also takes the table in pattern order and the offsets of every tile (the 32-row one gathers through perm)
             tr = int(L.lib.dd3d_conv_schedule_tile_rows(M1))
-            self.side.wait_event(ev_maps)
+            _wait_event(self.side, ev_maps, torch.cuda.current_stream(dev))
             with torch.cuda.stream(self.side):
                 # The schedule's outputs are ALLOCATED on the side stream too: its kernels wait for the maps only and run beside the first
                 # layer, so a block that the main stream's allocator pool had just taken back from a tensor of THIS step could still be
@@ -213,7 +233,7 @@ class _Pass:
                 L.call("dd3d_conv_schedule", L.ptr(k1), ld1, 27, M1, c1, L.ptr(perm1), L.ptr(tmap1), L.ptr(k1s), L.ptr(tmask1), L.ptr(ws), ws.numel(),
                        L.stream())
             self.sched = (perm1, tmap1, k1s, tmask1)
-            torch.cuda.current_stream(dev).wait_stream(self.side)
+            _wait(torch.cuda.current_stream(dev), self.side)
             if not self.static:
                 for t in self.sched:   # allocated on the side stream, read by both convolution launches on the main one
                     if t is not None:
@@ -232,7 +252,8 @@ class _Pass:
         prob, dl = self.prob, self.dl = _empty((B, J), dev), _empty((B, J), dev)
         closs, self.ce = _empty((B,), dev), _empty((G,), dev)
         # classifier, cross entropy, its logit gradient and the per-group bias gradient: two launches (dd3d_classifier_head)
-        g_cb = _empty((G, J), dev)
+        go = gw_out if gw_out is not None else [None] * 8
+        g_cb = go[7] if go[7] is not None else _empty((G, J), dev)
         ws = L.workspace(int(L.lib.dd3d_sparse_linear_ws_bytes(dp.M_bound, J)), dev)
         L.call("dd3d_classifier_head", L.ptr(P1), L.ptr(dp.site), L.ptr(dp.C), dp.M_bound, L.ptr(dp.seg_off), B, 128, None, L.ptr(Wsm), sst, J,
                L.ptr(cls_b), L.ptr(labels), L.ptr(group_cloud_off), G, int(self.max_per_group), L.ptr(logits), L.ptr(prob), L.ptr(dl), L.ptr(closs),
@@ -252,11 +273,11 @@ class _Pass:
 
         def classifier_gradients():
             side = cls_stream
-            side.wait_stream(main)
+            _wait(side, main)
             with torch.cuda.stream(side):
                 if self.dl_scale is not None:   # (the bias gradient of the SCALED logit gradients)
                     L.call("dd3d_group_sum_rows", L.ptr(dl), L.ptr(group_cloud_off), G, J, L.ptr(g_cb), L.stream())
-                g_cw = _empty((G, J, 128 * S), dev)
+                g_cw = go[6] if go[6] is not None else _empty((G, J, 128 * S), dev)
                 pst = _cw_strides(J, 128, S)
                 L.call("dd3d_sparse_linear_bwd_w", L.ptr(dl), L.ptr(P1), L.ptr(dp.vox_at), S, B, L.ptr(group_cloud_off), G, 128, J, L.ptr(g_cw), pst,
                        g_cw.numel(), L.stream())
@@ -274,9 +295,10 @@ class _Pass:
         sl_bwd_x_call(dl, dp, None, Wsm, sst, J, 0, gP1)
         # the ReLU-masked pooled gradients (ga) are kept for the synthetic clouds only: the second-order pass needs nothing else
         Ns = max(self.N_syn, 1)
-        self.ga1, self.ga0 = _empty((Ns, 128), dev), _empty((Ns, 128), dev)
+        self.ga1, self.ga0 = (_empty((Ns, 128), dev), _empty((Ns, 128), dev)) if self.B_syn > 0 else (None, None)   # (a pass without synthetic clouds keeps none)
         gY1, g_w5, g_b5 = self._arp_inorm_bwd(gP1, arg1, cm.parent(4), self._rows(1), is1, w5, b5, seg2, M1, B, G, self.ga1, self.B_syn, True,
-                                              dY_out=None if stash is None else stash["gY1"][:M1], gb_out=None if stash is None else stash["g_b5"])
+                                              dY_out=None if stash is None else stash["gY1"][:M1], gb_out=go[5] if stash is None else stash["g_b5"],
+                                              gw_out=go[4])
         # Two launches want the matrix cores here: the input gradient of the 128-channel convolution (main stream, everything else waits
         # for it) and its kernel gradient (side stream, only the loss value waits for it).  Side by side they share the pipe and BOTH take
         # ~400 us; with the kernel gradient held back until the input gradient is done (DD3D_BWW_AFTER, default) the main stream gets the
@@ -290,9 +312,9 @@ class _Pass:
             ev_l2 = torch.cuda.Event()
             ev_l2.record(main)
         if not after and not defer:
-            side.wait_stream(main)
+            _wait(side, main)
             with torch.cuda.stream(side):
-                g_W1 = self._bww(P0, 128, gY1, k1, ld1, M1, gro2, seg2)
+                g_W1 = self._bww(P0, 128, gY1, k1, ld1, M1, gro2, seg2, out=go[3])
         gP0 = _empty((M1, 128), dev)
         if self.sched is not None:
             L.call("dd3d_conv128_ordered", L.ptr(gY1), M1, L.ptr(W1t), L.ptr(k1), ld1, 27, M1, c1, 1, L.ptr(self.sched[0]), L.ptr(self.sched[1]),
@@ -309,25 +331,24 @@ class _Pass:
             self.early_out = early(self, ev_l2)
         late = os.environ.get("DD3D_BWW_LATE", "0") != "0"   # (measurement) the 128-channel kernel gradient behind the norm / pool backward of level 1
         if after and not defer and not late:
-            side.wait_stream(main)
+            _wait(side, main)
             with torch.cuda.stream(side):
-                g_W1 = self._bww(P0, 128, gY1, k1, ld1, M1, gro2, seg2)
+                g_W1 = self._bww(P0, 128, gY1, k1, ld1, M1, gro2, seg2, out=go[3])
         gY0, g_w1, g_b1 = self._arp_inorm_bwd(gP0, arg0, cm.parent(2), self._rows(0), is0, w1, b1, seg1, M0, B, G, self.ga0, self.B_syn, True,
-                                              dY_out=None if stash is None else stash["gY0"][:M0], gb_out=None if stash is None else stash["g_b1"])
+                                              dY_out=None if stash is None else stash["gY0"][:M0], gb_out=go[2] if stash is None else stash["g_b1"],
+                                              gw_out=go[1])
         if after and not defer and late:
-            side.wait_stream(main)
+            _wait(side, main)
             with torch.cuda.stream(side):
-                g_W1 = self._bww(P0, 128, gY1, k1, ld1, M1, gro2, seg2)
+                g_W1 = self._bww(P0, 128, gY1, k1, ld1, M1, gro2, seg2, out=go[3])
         # The first layer's kernel gradient feeds nothing but the loss VALUE either: it runs on a stream of its own next to the 128-channel
         # one (bandwidth-bound next to matrix-bound), and the main stream goes on to the matching loss of the differentiable entries and
         # the second-order pass (the caller joins the streams: FusedDistiller._compute)
         side2 = self.side2   # (queued behind the 128-channel kernel gradient on the same stream instead: 1.385 against 1.338 ms)
-        if os.environ.get("DD3D_W0_CHAIN", "0") != "0":   # (measurement)
-            side2 = self.side2 = side
         if not defer:
-            side2.wait_stream(main)
+            _wait(side2, main)
             with torch.cuda.stream(side2):
-                g_W0 = self._bww(F0, 3, gY0, k0, ld0, M0, gro1)
+                g_W0 = self._bww(F0, 3, gY0, k0, ld0, M0, gro1, out=go[0])
         if not self.static:
             for t in (g_cb, g_cw, g_W1, g_W0):   # allocated on the side stream, consumed on the main one
                 if t is not None:
@@ -359,14 +380,14 @@ class _Pass:
     xh1 = property(lambda self: self._xhat(1))
 
     def _arp_inorm_bwd(self, g_pool, arg, parent, rows, inv_std, w, b, seg, M_in, B, G, ga_out, ga_clouds, want_gw, ga_prev=None, gw_extra=None,
-                       dY_out=None, gb_out=None):
+                       dY_out=None, gb_out=None, gw_out=None):
         """Backward of max-pool -> ReLU -> affine -> instance norm in one pass per cloud, over the first B clouds:
         (dY, d weight [G,128], d bias [G,128]); ``ga_out`` receives the masked pooled gradient of the first ``ga_clouds`` clouds.
         ``rows`` = (xhat, None) or (Y, mean): see _rows."""
         dev = self.dev
         xhat, mean = rows
         dY = dY_out if dY_out is not None else _empty((M_in, 128), dev)
-        gw_w = _empty((G, 128), dev) if want_gw else None
+        gw_w = (gw_out if gw_out is not None else _empty((G, 128), dev)) if want_gw else None
         gw_b = (gb_out if gb_out is not None else _empty((G, 128), dev)) if want_gw else None
         ws = L.workspace(int(L.lib.dd3d_arp_inorm_bwd_ws_bytes(B)), dev)
         head = (L.ptr(g_pool), L.ptr(arg), L.ptr(parent), L.ptr(xhat)) + ((L.ptr(mean),) if mean is not None else ())
@@ -375,8 +396,8 @@ class _Pass:
                L.ptr(gw_b), L.ptr(ws), ws.numel(), L.stream())
         return dY, gw_w, gw_b
 
-    def _bww(self, X, Cin, dY, nbr, ld, M, gro, seg=None):
-        return conv_kernel_gradient(X, Cin, dY, nbr, ld, M, gro, self.G, self.dev, seg if self.small_clouds else None, self.B, self.cm.err)
+    def _bww(self, X, Cin, dY, nbr, ld, M, gro, seg=None, out=None):
+        return conv_kernel_gradient(X, Cin, dY, nbr, ld, M, gro, self.G, self.dev, seg if self.small_clouds else None, self.B, self.cm.err, out=out)
 
 
 
@@ -557,7 +578,7 @@ class FusedDistiller:
     def __init__(self, images_all, indices_class, network, ipc, num_classes=10, num_points=250, batch_size=256, dist_opt="modmse",
                  dist_lr=0.1, device=None, seed=0, image_syn=None, classes=None, momentum=0.5, graph=True, real_clouds=None,
                  quantization_size=1.0, clamp_range=(0.0, 27.0), zero_first_axis=True, defer_loss=False, real_classes=None, real_part=(0, 1),
-                 exchange=None):
+                 exchange=None, pipeline=None):
         """``real_classes`` / ``real_part`` / ``exchange``: the second sharding level.  This process computes the
         real-batch gradients of ``real_classes`` (default: its own ``classes``; must contain them) over part ``real_part = (p, P)`` of
         every sampled batch -- clouds p, p + P, ... of the SAME permutation every process of the group draws (same ``seed``) --
@@ -641,6 +662,10 @@ class FusedDistiller:
         self._graph = self._static = None
         self._graph_stamp, self._needs_eager, self._last_loss = None, False, None
         self._scope = "graph%x" % id(self)
+        # Pipelined step (``pipeline=True`` / DD3D_PIPELINE=1; see _pipe_body): the real and the synthetic batch as TWO passes, the real pass
+        # of step t+1 beside the synthetic pass of step t
+        self.pipeline = ((os.environ.get("DD3D_PIPELINE", "0") != "0") if pipeline is None else bool(pipeline)) and G > 0 and not self.split and not self.defer
+        self._pipe = None
         self.prefetch = True   # eager mode: sample the next step's real batch right behind this step (ChunkedDistiller: off, the chunks share one sample stream)
         self.so_early = os.environ.get("DD3D_SO_EARLY", "1") != "0"   # second-order pass started next to the first-order tail (_compute_gen)
         self._counters = _group_counters(dev, G + self.Gr)   # this distiller's own (its graphs keep the address)
@@ -715,7 +740,7 @@ class FusedDistiller:
             warnings.warn("FusedDistiller.close(): synchronisation failed: %r" % (e,))
         self._graph, self._graphs, self._pending, self._stash, self._prefetched = None, [None, None], None, None, None
         self.last = {}
-        self._static = None
+        self._static = self._pipe = None
         L.drop_scope(self._scope)
         after = L.hip_last_error()
         if before or after:
@@ -881,6 +906,130 @@ class FusedDistiller:
             st.pin_floor[i].numpy()[:] = self._floor_np
             st.gmin_floor.copy_(st.pin_floor[i], non_blocking=True)
         st.pin_ev[i].record()
+
+
+    # ------------------------------------------------------------------ pipelined step: two passes, the real one a step ahead
+    def _build_pipe(self):
+        """Fixed-address buffers of the pipelined step: the real batch and the synthetic batch as separate batches, and TWO sets of the
+        real batches' gradient lists (a real pass writes one while the synthetic pass of the step before reads the other)."""
+        if self._static is None:
+            self._build_static()
+        st, dev, G, ipc, npts = self._static, self.device, self.G, self.ipc, self.num_points
+        Bs, Ns = G * ipc, G * ipc * npts
+        pp = type("Pipe", (), {})()
+        i32 = lambda *shape: torch.zeros(shape, dtype=_I32, device=dev)
+        pp.rcoords, pp.rfeats = torch.zeros((st.bound, 4), device=dev), torch.zeros((st.bound, 3), device=dev)
+        pp.rpt_off, pp.rn, pp.rerr = i32(st.B + 1), i32(1), i32(1)
+        pp.rlabels = torch.tensor(np.repeat(self.real_classes, st.sizes), device=dev, dtype=_I32)
+        pp.rgroup = torch.tensor(np.repeat(np.arange(self.Gr), st.sizes), device=dev, dtype=_I32)
+        pp.rgco = torch.tensor(np.concatenate([[0], np.cumsum(st.sizes)]), device=dev, dtype=_I32)
+        pp.scoords, pp.sfeats = torch.zeros((Ns, 4), device=dev), torch.zeros((Ns, 3), device=dev)
+        pp.scoords[:, 0] = self.syn_batch_col[:, 0]
+        extent = self.site_extent()
+        J, S = self.network.classifier.weight.shape[0], extent[0] * extent[1] * extent[2]
+        shapes = [(27, 3, 128), (128,), (128,), (27, 128, 128), (128,), (128,), (J, 128 * S), (J,)]
+        pp.gwr = [[torch.zeros((self.Gr,) + sh, device=dev) for sh in shapes] for _ in range(2)]
+        pp.counters_r, pp.counters_s = _group_counters(dev, self.Gr), _group_counters(dev, G)
+        pp.extent, pp.graphs, pp.steps = extent, [None, None], 0
+        self._pipe = pp
+
+    def _pipe_gather(self):
+        st, pp = self._static, self._pipe
+        L.call("dd3d_gather_clouds", L.ptr(st.pool_xyz), L.ptr(st.pool_off), st.n_pool, L.ptr(st.ids), st.B, self.num_points, st.bound, 0, 0, self.quant,
+               L.ptr(pp.rcoords), L.ptr(pp.rfeats), L.ptr(pp.rpt_off), L.ptr(pp.rn), L.ptr(st.err), L.stream())
+
+    def _pipe_real_pass(self, out_set):
+        """The real batches that _pipe_gather assembled (the sample whose ids are in the static id buffer): maps, forward, first-order
+        backward on the CURRENT stream (+ the side stream for the parameter gradients that only the loss reads); their eight gradient
+        lists go into set ``out_set``."""
+        st, pp, dev = self._static, self._pipe, self.device
+        pr = _Pass(self.network, pp.rcoords, st.B, self.Gr, pp.rgroup, pp.rgco, 0, 0, self.stream_side, pp.rn, True, pp.rpt_off, self.num_points, pp.extent,
+                   self.stream_side, None, Gs=0, max_per_group=st.max_per, counters=pp.counters_r, feats3=pp.rfeats)
+        pr.run(pp.rfeats, pp.rlabels, gw_out=pp.gwr[out_set])
+        torch.cuda.current_stream(dev).wait_stream(self.stream_side)
+        return pr
+
+    def _pipe_syn_pass(self, in_set):
+        """Clamp, the synthetic batch, its forward and first-order backward, the matching loss against the real gradient lists of set
+        ``in_set``, the second-order backward into the points and the update -- all on the CURRENT stream (one stream: this pass is a chain
+        of small launches that runs beside the real pass)."""
+        pp, dev, G, ipc, npts = self._pipe, self.device, self.G, self.ipc, self.num_points
+        cur = torch.cuda.current_stream(dev)
+        cr = self.clamp_range
+        L.call("dd3d_syn_head", L.ptr(self.image_syn), self.image_syn.shape[0], npts, L.ptr(self.dest_cloud), int(cr is not None),
+               float(cr[0]) if cr else 0.0, float(cr[1]) if cr else 0.0, int(self.zero_first_axis), self.quant, L.ptr(pp.scoords), L.ptr(pp.sfeats), L.stream())
+        ps = _Pass(self.network, pp.scoords, G * ipc, G, self.syn_group, self.syn_gco, G * ipc, G * ipc * npts, cur, None, True, self.syn_pt_off, npts, pp.extent,
+                   cur, None, Gs=G, max_per_group=ipc, counters=pp.counters_s, feats3=pp.sfeats)
+        ps.run(pp.sfeats, self.syn_labels)
+        need = [i in (1, 4, 6, 7) for i in range(8)]
+        loss_g, d = grouped_match_loss(ps.gw, pp.gwr[in_set], self.dist_opt, G, need)
+        dfeats = ps.backward_to_points(d[1], d[4], d[6], d[7], ipc)
+        grad = torch.empty_like(self.image_syn)
+        L.call("dd3d_sgd_scatter", L.ptr(self.image_syn), L.ptr(self.momentum_buf), L.ptr(dfeats), L.ptr(self.dest_cloud), self.image_syn.shape[0], npts,
+               self.lr, self.momentum, L.ptr(grad), L.stream())
+        return ps, loss_g, grad, loss_g.sum()
+
+    def _pipe_body(self, parity):
+        """One pipelined step: the synthetic pass of THIS step (third stream; it reads the real gradient lists of set ``parity``, written one
+        step ago) beside the real pass of the NEXT step's sample (main + second stream; it writes set ``1 - parity``).  Exact: the network
+        is frozen for the whole run (mnist_distill.py:262: the inner loop is declared and never run), so a real batch's gradient lists
+        depend on its sample only.  Only main <-> side and main <-> third-stream waits (what the capture tolerates on ROCm 7.2)."""
+        pp, dev = self._pipe, self.device
+        main, syn_stream = torch.cuda.current_stream(dev), self.stream_side2
+        with L.ws_scope(self._scope + "pipe"):
+            self._pipe_gather()   # (the fork comes behind the main stream's first launch: a fork from a capture stream that has no node yet crashed the capture)
+            syn_stream.wait_stream(main)
+            # (a HIP graph dispatches in capture order and a branch captured first holds back the one captured after it: DD3D_PIPE_ORDER
+            # chooses which pass is enqueued first)
+            if os.environ.get("DD3D_PIPE_ORDER", "syn") == "syn":
+                with torch.cuda.stream(syn_stream):
+                    ps, loss_g, grad, total = self._pipe_syn_pass(parity)
+                pr = self._pipe_real_pass(1 - parity)
+            else:
+                pr = self._pipe_real_pass(1 - parity)
+                with torch.cuda.stream(syn_stream):
+                    ps, loss_g, grad, total = self._pipe_syn_pass(parity)
+            main.wait_stream(syn_stream)
+        self.last = {"per_class": loss_g, "grad": grad, "gw_real": _GradList(pp.gwr[parity], self.network.dense_extent, pp.extent),
+                     "gw_syn": _GradList([t for t in ps.gw], self.network.dense_extent, pp.extent), "logits": (None, ps.logits),
+                     "conv1_maps": [(p_.maps[4], p_.M[1], p_.cnt[1]) for p_ in (ps, pr)], "passes": (ps, pr)}
+        return total
+
+    def _outer_step_pipelined(self):
+        """Host side of the pipelined step.  Step 0 primes the pipe eagerly: real pass of sample 0, then a body (synthetic pass 0 beside the
+        real pass of sample 1); from step 1 on the body of parity t % 2 is captured once and replayed.  The host draws sample t + 1 before
+        step t -- the same stream of draws as the merged step's, one draw earlier."""
+        if self._pipe is None:
+            self._build_pipe()
+        pp = self._pipe
+        if pp.steps > 0 and self._param_stamp() != self._graph_stamp:
+            raise RuntimeError("the pipelined step holds gradient lists of a real batch computed with the old weights; build a new distiller after a weight change")
+        if pp.steps == 0:
+            self._graph_stamp = self._param_stamp()
+            self._upload_ids()
+            with L.ws_scope(self._scope + "pipe"):
+                self._pipe_gather()
+                pr0 = self._pipe_real_pass(0)
+            torch.cuda.synchronize(self.device)   # (once: the priming pass's buffers go back to the allocator only when its launches are done)
+            del pr0
+        self._upload_ids()   # the sample of the NEXT step
+        parity = pp.steps % 2
+        if pp.steps == 0 or not self.use_graph:
+            loss = self._pipe_body(parity)
+        elif pp.graphs[parity] is None:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                loss = self._pipe_body(parity)
+            pp.graphs[parity] = (g, loss, self.last)
+            self._graph = g
+            g.replay()
+        else:
+            g, loss, self.last = pp.graphs[parity]
+            g.replay()
+        pp.steps += 1
+        self.steps_done += 1
+        self._last_loss = loss
+        return loss
 
     # ------------------------------------------------------------------ the step
     def _merge_eager(self, rb, xyz):
@@ -1151,6 +1300,8 @@ class FusedDistiller:
                 raise RuntimeError("this FusedDistiller has taken steps on a stream of another priority; use one stream priority per distiller")
             self.stream_side, self.stream_side2, self.stream_data = (torch.cuda.Stream(self.device, priority=prio) for _ in range(3))
             self.stream_defer = self.stream_side2
+        if self.pipeline and real_batch is None and apply_update:
+            return self._outer_step_pipelined()
         if self.use_graph and real_batch is None and apply_update:
             if self._static is None:
                 self._build_static()

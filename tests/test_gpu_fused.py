@@ -576,6 +576,35 @@ def test_cfg4_full_shape_step_properties():
             assert torch.equal(cm.kernel_map(*m)[0][:, :Mo], rm[:, :Mo]), m
 
 
+@pytest.mark.parametrize("metric", ["modmse", "ours"])
+def test_pipelined_step_equals_the_merged_step(metric):
+    """pipeline=True: the real and the synthetic batch as two passes, the real pass of step t+1 beside the synthetic pass of step t (exact:
+    the network is frozen, a real batch's gradient lists depend on its sample only).  Against the merged step on the same seed: the same
+    samples in the same order (drawn one step earlier), loss / per-class losses / xyz gradient / updated points / both gradient lists equal
+    to fp32 rounding (other partitions of the kernel-gradient sums) over five steps; the captured pipeline equals the eagerly enqueued one
+    bit for bit; the real gradient lists a step uses are those of ITS sample, not of the one being computed beside it."""
+    from dd3d_amd.fused_step import FusedDistiller
+    from dd3d_amd.synthetic import mnist3d_like
+    images, _, idx = mnist3d_like(4, 40, seed=3)
+    syn = init_synthetic(4, 3, 250, seed=1)
+    kw = dict(ipc=3, num_classes=4, batch_size=24, dist_opt=metric, device=DEV, seed=11, image_syn=syn)
+    with FusedDistiller(images, idx, _net(), graph=False, **kw) as fm, FusedDistiller(images, idx, _net(), graph=True, pipeline=True, **kw) as fp, \
+            FusedDistiller(images, idx, _net(), graph=False, pipeline=True, **kw) as fq:
+        for step in range(5):
+            lm, lp, lq = fm.outer_step(), fp.outer_step(), fq.outer_step()
+            assert lp.item() == lq.item() and torch.equal(fp.image_syn, fq.image_syn), f"step {step}: captured pipeline != eager pipeline"
+            assert rel_err(lp.reshape(1), lm.reshape(1)) < 1e-5, (step, lp.item(), lm.item())
+            assert rel_err(fp.last["per_class"], fm.last["per_class"]) < 1e-5
+            assert rel_err(fp.last["grad"], fm.last["grad"]) < 5e-5
+            assert rel_err(fp.image_syn, fm.image_syn) < 1e-6
+            for i in range(8):
+                assert rel_err(fp.last["gw_real"][i].reshape(-1), fm.last["gw_real"][i].reshape(-1)) < 2e-5, (step, i)
+                assert rel_err(fp.last["gw_syn"][i].reshape(-1), fm.last["gw_syn"][i].reshape(-1)) < 2e-5, (step, i)
+        fp.check()
+        fq.check()
+        assert fp._pipe.graphs[0] is not None and fp._pipe.graphs[1] is not None
+
+
 def test_chunked_distiller_equals_one_batch():
     """ChunkedDistiller (class chunks in sequence on one device, what bench.py runs for BASELINE configs[4]) against one FusedDistiller over
     all classes: the classes are independent inside a step, so losses, gradients and updated points agree to fp32 rounding (the row-chunk /
