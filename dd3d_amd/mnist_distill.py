@@ -99,6 +99,37 @@ class Distiller:
         return loss.detach()
 
 
+def inner_network_update(network, image_syn, label_syn, optimizer_net, ipc, classes=None, device=None, quantization_size=1, group=None):
+    """One inner-loop update of the NETWORK on the synthetic set -- the other half of gradient matching (Zhao et al.), which the reference
+    declares (``outer_loop, inner_loop = 1, 1``, mnist_distill.py:262) and never runs: its network stays at its initialisation, so there is
+    no reference behaviour to match here.  What it does follows the loop's own synthetic forward (mnist_distill.py:351-355): one batch per
+    class -- that class's ``ipc`` synthetic clouds through ``create_input_batch`` and the network, placed by that batch's own minimum corner
+    (MEConv.py:251-254) -- mean cross entropy per class, averaged over all classes, then ``optimizer_net.step()``.
+    Class-sharded (``classes`` = the classes this process owns; default all): every rank sums its own classes' terms, and the parameter
+    gradients are summed over the ranks (``sharding.all_reduce_gradients``: one 5.83 MB all-reduce over RCCL) before the step, so every
+    rank takes the step a single process would take -- exactly, since a class's batch never spans ranks.
+    A FusedDistiller notices the changed weights by itself (parameter version counters) and re-captures its graph.  Returns this rank's
+    share of the loss (detached)."""
+    from .sharding import all_reduce_gradients
+    from .utils.MinkowskiCollate import minkowski_collate_fn
+    dev = torch.device(device or settings.device)
+    num_classes = int(image_syn.shape[0]) // ipc
+    classes = list(range(num_classes)) if classes is None else list(classes)
+    optimizer_net.zero_grad()
+    total = None
+    for c in classes:
+        syn = image_syn.detach()[c * ipc:(c + 1) * ipc]
+        lab = label_syn[c * ipc:(c + 1) * ipc]
+        batch = minkowski_collate_fn([{"coordinates": syn[i], "features": syn[i], "label": lab[i].reshape(1)} for i in range(ipc)])
+        out = network(create_input_batch(batch, True, device=dev, quantization_size=quantization_size))
+        loss = nn.functional.cross_entropy(out, batch["labels"].to(out.device).long()) / num_classes
+        loss.backward()
+        total = loss.detach() if total is None else total + loss.detach()
+    all_reduce_gradients(network.parameters(), group)
+    optimizer_net.step()
+    return total
+
+
 def main(argv=None, ini_path="configs/default.ini"):
     """The reference's ``__main__`` (mnist_distill.py:251-410) on MNIST-shaped synthetic digits: matching steps, the evaluation block at
     the reference's iterations (:276, :320-330), checkpoint + .ply export every ``save_cad_every`` iterations (:383-402).

@@ -94,3 +94,26 @@ def all_reduce_in(group):
     def exchange(flat: torch.Tensor):
         _all_reduce(flat, dist.ReduceOp.SUM, group)
     return exchange
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Inner-loop network update: gradients of the network parameters summed over the ranks
+# ---------------------------------------------------------------------------------------------------------------------
+def all_reduce_gradients(params, group=None):
+    """``p.grad`` of every parameter summed over the ranks, in place: ONE flat fp32 buffer (MEConvExp: 1 456 778 floats = 5.83 MB), ONE
+    all-reduce -- over seven 153 GB/s xGMI links a message of this size is latency-bound, so nothing is gained by bucketing it.  RCCL on the
+    GPUs, gloo in the CPU tests; a no-op for a single process.  Parameters without a gradient contribute zeros."""
+    params = [p for p in params]
+    if not is_distributed() or not params:
+        return
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+    _all_reduce(flat, dist.ReduceOp.SUM, group)
+    off = 0
+    for p in params:
+        n = p.numel()
+        g = flat[off:off + n].view_as(p)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        off += n

@@ -153,6 +153,53 @@ def test_meconvexp_step_vs_oracle_midsize(metric):
             assert rel_err(a, b) < 1e-4
 
 
+def test_inner_network_update_vs_oracle_and_class_shards():
+    """The inner-loop network update (no reference behaviour: mnist_distill.py:262 declares the loop and never runs it) follows the loop's
+    per-class synthetic forward (:351-355).  Checked against the fp64 oracle restating the same thing, and: the parameter gradients of two
+    class shards sum to the whole set's (what the all-reduce of sharding.all_reduce_gradients adds up over RCCL)."""
+    from oracle import minkowski_ref as ME
+    from dd3d_amd.mnist_distill import inner_network_update
+    from dd3d_amd.models.MEConv import MEConvExp
+    nclass, ipc = 4, 2
+    net = _load(MEConvExp, R.MEConvExp, False)
+    onet = R.MEConvExp(in_channel=3, out_channel=10)
+    onet.load_state_dict(det_state_dict(onet, "net.MEConvExp"))
+    onet = onet.double().train()
+    image_syn = init_synthetic(nclass, ipc, num_points=250, seed=9)
+    R.clamp_synthetic_(image_syn)                  # mnist_distill.py:311-317, as at the top of every iteration
+    image_syn = image_syn.to(DEV)
+    label_syn = torch.arange(nclass, device=DEV).repeat_interleave(ipc)
+    osyn = image_syn.detach().cpu().double()
+    oopt = torch.optim.SGD(onet.parameters(), lr=0.01, momentum=0.5)
+    oopt.zero_grad()
+    oloss = 0.0
+    for c in range(nclass):
+        items = [osyn[c * ipc + i] for i in range(ipc)]
+        lab = torch.full((ipc,), c, dtype=torch.long)
+        c_, f_, l_ = ME.sparse_collate(items, items, [lab[i].reshape(1) for i in range(ipc)], dtype=torch.float64)
+        out = onet(R.create_input_batch({"coordinates": c_, "features": f_, "labels": l_}, True, device="cpu", quantization_size=1,
+                                        coord_dtype=torch.float32))
+        l = torch.nn.functional.cross_entropy(out, l_) / nclass
+        l.backward()
+        oloss += float(l.detach())
+    ograd = [p.grad.clone() for p in onet.parameters()]
+    oopt.step()
+    # class shards first (lr 0: the weights stay), then the whole set with the real step
+    shard = []
+    for mine in ([0, 2], [1, 3]):
+        opt0 = torch.optim.SGD(net.parameters(), lr=0.0)
+        ls = inner_network_update(net, image_syn, label_syn, opt0, ipc, classes=mine, device=DEV)
+        shard.append(([p.grad.clone() for p in net.parameters()], float(ls)))
+    opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.5)
+    loss = inner_network_update(net, image_syn, label_syn, opt, ipc, device=DEV)
+    assert float(loss) == pytest.approx(oloss, rel=1e-4) and shard[0][1] + shard[1][1] == pytest.approx(float(loss), rel=1e-5)
+    for p, g0, g1, og in zip(net.parameters(), shard[0][0], shard[1][0], ograd):
+        assert rel_err(p.grad, og) < 1e-4
+        assert rel_err(g0 + g1, p.grad) < 1e-5
+    for p, op in zip(net.parameters(), onet.parameters()):
+        assert rel_err(p.detach(), op.detach()) < 1e-5
+
+
 def test_batch_from_images_equals_per_item_collate():
     from dd3d_amd.utils.Mnist2D import Mnist2Dreal, batch_from_images, get_mnist_dataloader
     g = np.load(os.path.join(G, "g2_plumbing.npz"))

@@ -52,6 +52,48 @@ def test_class_sharding_world2_gloo():
     assert all(r[4] == expect for r in res)
 
 
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dd3d_amd.sharding import all_reduce_gradients
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+    unused = torch.nn.Parameter(torch.ones(4))                  # a parameter no loss term touches: grad None on every rank
+    x = torch.arange(40, dtype=torch.float32).reshape(8, 5) / 10.0
+    y = torch.arange(8) % 3
+    rows = torch.arange(rank, 8, world)
+    loss = torch.nn.functional.cross_entropy(net(x[rows]), y[rows], reduction="sum") / 8
+    loss.backward()
+    params = list(net.parameters()) + [unused]
+    all_reduce_gradients(params)
+    q.put((rank, [p.grad.tolist() for p in params]))
+    dist.destroy_process_group()
+
+
+def test_all_reduce_gradients_world2_gloo():
+    """Two ranks, each with half of a batch: after all_reduce_gradients every rank holds the whole batch's parameter gradients (the
+    inner-loop network update's exchange: one flat buffer, one SUM all-reduce); a parameter without a gradient comes back as zeros."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+    x = torch.arange(40, dtype=torch.float32).reshape(8, 5) / 10.0
+    torch.nn.functional.cross_entropy(net(x), torch.arange(8) % 3).backward()
+    for _, grads in res:
+        for g, p in zip(grads[:-1], net.parameters()):
+            assert torch.allclose(torch.tensor(g), p.grad, rtol=1e-5, atol=1e-7)
+        assert grads[-1] == [0.0] * 4
+    assert res[0][1] == res[1][1]                                # bitwise the same on both ranks: they take the same step
+
+
 def test_owned_classes_partition_any_world():
     from dd3d_amd.sharding import owned_classes
     for world in (1, 2, 4, 8, 16):
