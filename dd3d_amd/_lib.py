@@ -64,6 +64,11 @@ _SIGS = {
     "dd3d_conv128_bwd_weight_clouds_max_rows": (I32, []),
     "dd3d_conv128_bwd_weight_clouds_ws_bytes": (I64, [I64, I32]),
     "dd3d_conv128_bwd_weight_clouds": (I32, [P, P, P, I64, I32, I64, P, I32, P, I32, P, P, P, I64, P]),
+    "dd3d_conv_any_max_channels": (I32, []),
+    "dd3d_conv_any_fwd": (I32, [P, I64, I32, P, I32, P, I64, I32, I64, P, P, P]),
+    "dd3d_conv_any_bwd_data": (I32, [P, I64, P, I32, P, I32, P, I64, I32, P, P]),
+    "dd3d_conv_any_bwd_weight_ws_bytes": (I64, [I32, I32, I32]),
+    "dd3d_conv_any_bwd_weight": (I32, [P, I32, P, I32, P, I64, I32, I64, P, P, P, I64, P]),
     "dd3d_transpose_kernel": (I32, [P, I32, I32, I32, P, P]),
     "dd3d_voxel_mean_fwd": (I32, [P, I64, I32, P, P, I64, P, P, P]),
     "dd3d_voxel_mean_bwd": (I32, [P, I64, I32, P, P, I64, P, P]),

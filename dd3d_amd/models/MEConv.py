@@ -45,8 +45,9 @@ class MEConvExp(ME.MinkowskiNetwork):
     def forward(self, x: TensorField):
         out = x.sparse()
         cm = out.coordinate_manager
-        if not self.fused:
-            # op-by-op path: every torch-native piece of the reference stays torch-native (dense tensor included)
+        if not self.fused or ops.true_second_order_enabled():
+            # op-by-op path: every torch-native piece of the reference stays torch-native (dense tensor included); the only path of the
+            # true-second-order research mode (ops.true_second_order)
             out = self.features(out)
             B = cm.B
             shape = torch.Size([B, 128, *self.dense_extent])

@@ -50,9 +50,7 @@ class MinkowskiConvolution(nn.Module):
         if self.kernel_size == 1:   # (only the reference's unused variants: models/MEConv.py:39,52,116,130)
             return SparseTensor(ops.sparse_conv_any(x.F, self.kernel[None], None, 0, M), cm, ts)
         nbr, ld = cm.kernel_map(ts, ts, 3)
-        if self.out_channels == 128 and self.in_channels in (3, 128):
-            return SparseTensor(ops.SparseConvFn.apply(x.F, self.kernel, nbr, ld, M), cm, ts)
-        return SparseTensor(ops.sparse_conv_any(x.F, self.kernel, nbr, ld, M), cm, ts)
+        return SparseTensor(ops.sparse_conv_any(x.F, self.kernel, nbr, ld, M), cm, ts)   # every shape on hand-written kernels
 
     def __repr__(self):
         k = self.kernel_size
@@ -71,14 +69,10 @@ class MinkowskiInstanceNorm(nn.Module):
 
     def forward(self, x: SparseTensor) -> SparseTensor:
         cm, ts = x.coordinate_manager, x.tensor_stride
-        if self.num_features == 128:
+        if self.num_features == 128 and not ops.true_second_order_enabled():
             out = ops.InstanceNormFn.apply(x.F, cm.seg_off(ts), cm.B)
-        else:   # channel counts of the reference's unused MEConv stack (64, 32, 16): torch ops on the device, same formula
-            b = x.C[:, 0].to(torch.int64)
-            cnt = torch.bincount(b, minlength=cm.B).to(x.F.dtype).clamp_(min=1)[:, None]
-            seg = lambda t: torch.zeros((cm.B, t.shape[1]), dtype=t.dtype, device=t.device).index_add(0, b, t)
-            cen = x.F - (seg(x.F) / cnt)[b]
-            out = cen * (1.0 / torch.sqrt(seg(cen * cen) / cnt + 1e-8))[b]
+        else:   # channel counts of the reference's unused MEConv stack (64, 32, 16), and the true-second-order mode: torch ops on the device
+            out = ops.instance_norm_torch(x.F, x.C[:, 0].to(torch.int64), cm.B)
         return SparseTensor(out * self.weight + self.bias, cm, ts)
 
     def __repr__(self):
@@ -107,7 +101,10 @@ class MinkowskiMaxPooling(nn.Module):
     def forward(self, x: SparseTensor) -> SparseTensor:
         cm, ts = x.coordinate_manager, x.tensor_stride
         kids, ld = cm.kernel_map(ts, 2 * ts, 2)
-        out = ops.MaxPoolFn.apply(x.F, kids, ld, cm.parent(2 * ts), cm.num_rows(2 * ts))
+        if ops.true_second_order_enabled():
+            out = ops.max_pool_true(x.F, kids, ld, cm.num_rows(2 * ts))
+        else:
+            out = ops.MaxPoolFn.apply(x.F, kids, ld, cm.parent(2 * ts), cm.num_rows(2 * ts))
         return SparseTensor(out, cm, 2 * ts)
 
     def __repr__(self):
@@ -127,7 +124,10 @@ class MinkowskiAvgPooling(nn.Module):
     def forward(self, x: SparseTensor) -> SparseTensor:
         cm, ts = x.coordinate_manager, x.tensor_stride
         kids, ld = cm.kernel_map(ts, 2 * ts, 2)
-        out = ops.AvgPoolFn.apply(x.F, kids, ld, cm.parent(2 * ts), cm.num_rows(2 * ts))
+        if ops.true_second_order_enabled():
+            out = ops.avg_pool_torch(x.F, kids, cm.num_rows(2 * ts))
+        else:
+            out = ops.AvgPoolFn.apply(x.F, kids, ld, cm.parent(2 * ts), cm.num_rows(2 * ts))
         return SparseTensor(out, cm, 2 * ts)
 
     def __repr__(self):
@@ -144,6 +144,10 @@ class PooledBatch:
 class MinkowskiGlobalAvgPooling(nn.Module):
     def forward(self, x: SparseTensor) -> PooledBatch:
         cm, ts = x.coordinate_manager, x.tensor_stride
+        if ops.true_second_order_enabled():   # differentiable torch ops on the device
+            b = x.C[:, 0].to(torch.int64)
+            cnt = torch.bincount(b, minlength=cm.B).to(x.F.dtype).clamp_(min=1)[:, None]
+            return PooledBatch(torch.zeros((cm.B, x.F.shape[1]), dtype=x.F.dtype, device=x.F.device).index_add(0, b, x.F) / cnt, cm)
         return PooledBatch(ops.GlobalAvgPoolFn.apply(x.F, cm.seg_off(ts), cm.B), cm)
 
     def __repr__(self):

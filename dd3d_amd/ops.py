@@ -22,6 +22,34 @@ from .sparse import CoordinateManager
 
 _F32 = torch.float32
 
+# ----------------------------------------------------------------------------------------------- second-order mode
+# "me" (default): MinkowskiEngine's semantics, above.  "true" (an explicitly separate research mode): every
+# op between the loss and the weights is differentiated twice -- the convolutions through SparseConvTrueFn (its backward is a
+# Function with a backward of its own, all three on the HIP kernels), instance norm / ReLU / pooling through differentiable torch ops
+# on the device (the pooling winners still come from the HIP kernel).  Only the op-by-op path of the models honours it; the fused step
+# (fused_step.FusedDistiller) is the reference's semantics and nothing else.
+_TRUE_SECOND_ORDER = False
+
+
+class true_second_order:
+    """``with ops.true_second_order(): ...`` -- networks run inside differentiate the sparse ops twice (see above)."""
+
+    def __init__(self, enabled: bool = True):
+        self.enabled = bool(enabled)
+
+    def __enter__(self):
+        global _TRUE_SECOND_ORDER
+        self.prev, _TRUE_SECOND_ORDER = _TRUE_SECOND_ORDER, self.enabled
+        return self
+
+    def __exit__(self, *exc):
+        global _TRUE_SECOND_ORDER
+        _TRUE_SECOND_ORDER = self.prev
+
+
+def true_second_order_enabled() -> bool:
+    return _TRUE_SECOND_ORDER
+
 
 def _c(t: torch.Tensor) -> torch.Tensor:
     t = t.detach()
@@ -96,15 +124,54 @@ def conv_bwd_weight(X, dY, nbr, ld, M_out, group_row_off, G):
     return dW
 
 
+def _hot_shape(K, Cin, Cout) -> bool:
+    """The shapes of MEConvExp (models/MEConv.py:224): their own kernels (conv.hip, conv_bww_sk.hip); everything else: conv_any.hip."""
+    return K == 27 and Cout == 128 and Cin in (3, 128)
+
+
+def conv_fwd_raw(x, w, nbr, ld, M_out):
+    """Y[o] = sum_k x[nbr[k][o]] @ w[k] on raw (detached, contiguous fp32) buffers; nbr None: kernel_size 1 (every row its own neighbour)."""
+    K, Cin, Cout = w.shape
+    Y = torch.empty((M_out, Cout), dtype=_F32, device=x.device)
+    if _hot_shape(K, Cin, Cout):
+        L.call("dd3d_conv_fwd", L.ptr(x), x.shape[0], Cin, L.ptr(w), Cout, L.ptr(nbr), ld, K, M_out, None, 0, L.ptr(Y), L.stream())
+    else:
+        L.call("dd3d_conv_any_fwd", L.ptr(x), x.shape[0], Cin, L.ptr(w), Cout, L.ptr(nbr), ld, K, M_out, None, L.ptr(Y), L.stream())
+    return Y
+
+
+def conv_bwd_data_raw(g, w, nbr, ld, W_cache=None):
+    """dX[i] = sum over the pairs (k, o) with nbr[k][o] == i of g[o] @ w[k]^T (stride-1 convolution: input rows == output rows).
+    ``W_cache``: the tensor to hang the transposed kernel on (a parameter keeps it until its version counter moves)."""
+    K, Cin, Cout = w.shape
+    M = g.shape[0]
+    dX = torch.empty((M, Cin), dtype=_F32, device=g.device)
+    if _hot_shape(K, Cin, Cout):
+        wk = transposed_kernel(W_cache if W_cache is not None else w) if Cin == 128 else w
+        L.call("dd3d_conv_bwd_data", L.ptr(g), M, None, Cout, L.ptr(wk), Cin, L.ptr(nbr), ld, K, L.ptr(dX), L.stream())
+    else:
+        L.call("dd3d_conv_any_bwd_data", L.ptr(g), M, None, Cout, L.ptr(w), Cin, L.ptr(nbr), ld, K, L.ptr(dX), L.stream())
+    return dX
+
+
+def conv_bwd_weight_raw(x, g, nbr, ld, M_out, K):
+    """dW[k] = sum_o x[nbr[k][o]]^T g[o], [K, Cin, Cout]."""
+    Cin, Cout = x.shape[1], g.shape[1]
+    if _hot_shape(K, Cin, Cout):
+        return conv_bwd_weight(x, g, nbr, ld, M_out, _single_group(M_out, x.device), 1)[0]
+    dW = torch.empty((K, Cin, Cout), dtype=_F32, device=x.device)
+    ws = L.workspace(int(L.lib.dd3d_conv_any_bwd_weight_ws_bytes(K, Cin, Cout)), x.device)
+    L.call("dd3d_conv_any_bwd_weight", L.ptr(x), Cin, L.ptr(g), Cout, L.ptr(nbr), ld, K, M_out, None, L.ptr(dW), L.ptr(ws), ws.numel(), L.stream())
+    return dW
+
+
 class SparseConvFn(Function):
-    """ME.MinkowskiConvolution(kernel_size=3, stride=1, bias=False): Y[o] = sum_k X[nbr[k][o]] @ W[k]."""
+    """ME.MinkowskiConvolution(stride=1, bias=False): Y[o] = sum_k X[nbr[k][o]] @ W[k], W [K, Cin, Cout] (``nbr`` None: kernel_size 1).
+    Any channel widths up to 128.  The backward calls kernels on raw buffers: a constant under ``create_graph=True``, like MinkowskiEngine's."""
 
     @staticmethod
     def forward(ctx, X, W, nbr, ld, M_out):
-        x, w = _c(X), _c(W)
-        K, Cin, Cout = w.shape
-        Y = torch.empty((M_out, Cout), dtype=_F32, device=x.device)
-        L.call("dd3d_conv_fwd", L.ptr(x), x.shape[0], Cin, L.ptr(w), Cout, L.ptr(nbr), ld, K, M_out, None, 0, L.ptr(Y), L.stream())
+        Y = conv_fwd_raw(_c(X), _c(W), nbr, ld, M_out)
         ctx.save_for_backward(X, W)
         ctx.nbr, ctx.ld, ctx.M_out = nbr, ld, M_out
         return Y
@@ -113,15 +180,83 @@ class SparseConvFn(Function):
     def backward(ctx, g):
         X, W = ctx.saved_tensors
         x, w, g = _c(X), _c(W), _c(g)
-        K, Cin, Cout = w.shape
         dX = dW = None
         if ctx.needs_input_grad[0]:
-            dX = torch.empty_like(x)
-            wk = transposed_kernel(W) if Cin == 128 else w
-            L.call("dd3d_conv_bwd_data", L.ptr(g), x.shape[0], None, Cout, L.ptr(wk), Cin, L.ptr(ctx.nbr), ctx.ld, K, L.ptr(dX), L.stream())
+            dX = conv_bwd_data_raw(g, w, ctx.nbr, ctx.ld, W)
         if ctx.needs_input_grad[1]:
-            dW = conv_bwd_weight(x, g, ctx.nbr, ctx.ld, ctx.M_out, _single_group(ctx.M_out, x.device), 1)[0]
+            dW = conv_bwd_weight_raw(x, g, ctx.nbr, ctx.ld, ctx.M_out, w.shape[0])
         return dX, dW, None, None, None
+
+
+class SparseConvTrueFn(Function):
+    """SparseConvFn for the true-second-order research mode: the same forward; the backward is ``_ConvGradFn``, a Function with a backward
+    of its own, so gradients of gradients flow through the convolution (and, since that backward is again made of these two Functions,
+    to any order)."""
+
+    @staticmethod
+    def forward(ctx, X, W, nbr, ld, M_out):
+        Y = conv_fwd_raw(_c(X), _c(W), nbr, ld, M_out)
+        ctx.save_for_backward(X, W)
+        ctx.nbr, ctx.ld, ctx.M_out = nbr, ld, M_out
+        return Y
+
+    @staticmethod
+    def backward(ctx, g):
+        X, W = ctx.saved_tensors
+        dX, dW = _ConvGradFn.apply(g, X, W, ctx.nbr, ctx.ld, ctx.M_out, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return dX, dW, None, None, None
+
+
+class _ConvGradFn(Function):
+    """(g, X, W) -> (dX, dW) of a stride-1 sparse convolution: dX = sum_k scatter(g W[k]^T), dW[k] = X_k^T g (X_k = the rows gathered by
+    offset k).  Both are bilinear, so the backward is made of the same three kernels:
+      cotangent ggX of dX:  d g = conv(ggX, W),  d W[k] = ggX_k^T g;      cotangent ggW of dW:  d g += conv(X, ggW),  d X = bwd_data(g, ggW)."""
+
+    @staticmethod
+    def forward(ctx, g, X, W, nbr, ld, M_out, want_dx, want_dw):
+        gq, x, w = _c(g), _c(X), _c(W)
+        dX = conv_bwd_data_raw(gq, w, nbr, ld, W) if want_dx else None
+        dW = conv_bwd_weight_raw(x, gq, nbr, ld, M_out, w.shape[0]) if want_dw else None
+        ctx.save_for_backward(g, X, W)
+        ctx.meta = (nbr, ld, M_out)
+        return dX, dW
+
+    @staticmethod
+    def backward(ctx, ggX, ggW):
+        g, X, W = ctx.saved_tensors
+        meta = ctx.meta
+        need_g, need_x, need_w = ctx.needs_input_grad[:3]
+        d_g = d_x = d_w = None
+        if ggX is not None:
+            if need_g:
+                d_g = SparseConvTrueFn.apply(ggX, W, *meta)
+            if need_w:
+                d_w = _ConvGradFn.apply(g, ggX, W, *meta, False, True)[1]
+        if ggW is not None:
+            if need_g:
+                t = SparseConvTrueFn.apply(X, ggW, *meta)
+                d_g = t if d_g is None else d_g + t
+            if need_x:
+                d_x = _ConvGradFn.apply(g, X, ggW, *meta, True, False)[0]
+        return d_g, d_x, d_w, None, None, None, None, None
+
+
+def max_pool_true(X, kids, ld, M_out):
+    """MinkowskiMaxPooling(2, 2) for the true-second-order mode: the winners come from the HIP kernel, the values from a differentiable gather."""
+    x = _c(X)
+    out = torch.empty((M_out, x.shape[1]), dtype=_F32, device=x.device)
+    arg = torch.empty((M_out, x.shape[1]), dtype=torch.int32, device=x.device)
+    L.call("dd3d_affine_relu_pool_fwd", L.ptr(x), None, None, 0, x.shape[1], L.ptr(kids), ld, kids.shape[0], M_out, None, L.ptr(out), L.ptr(arg), L.stream())
+    return X.gather(0, arg.long())
+
+
+def instance_norm_torch(F, b, B):
+    """MinkowskiInstanceNorm's normalisation (biased variance, eps = 1e-8 inside the sqrt) as differentiable torch ops on the device:
+    the channel counts no HIP kernel takes (64, 32, 16: the reference's unused MEConv stack) and the true-second-order mode."""
+    cnt = torch.bincount(b, minlength=B).to(F.dtype).clamp_(min=1)[:, None]
+    seg = lambda t: torch.zeros((B, t.shape[1]), dtype=t.dtype, device=t.device).index_add(0, b, t)
+    cen = F - (seg(F) / cnt)[b]
+    return cen * (1.0 / torch.sqrt(seg(cen * cen) / cnt + 1e-8))[b]
 
 
 # ----------------------------------------------------------------------------------------------- instance norm (stand-alone)
@@ -182,21 +317,22 @@ class MaxPoolFn(Function):
 
 # ----------------------------------------------------------------------------------------------- the reference's unused variants (f4)
 def sparse_conv_any(X, W, nbr, ld, M_out):
-    """MinkowskiConvolution for the channel counts and kernel sizes that only the reference's UNUSED models name (models/MEConv.py:
-    25-39,102-130: 1 -> 128, 128 -> 64 -> 32 -> 16, 1x1 convolutions): Y[o] = sum_k X[nbr[k][o]] @ W[k] as gathers + library GEMMs on the
-    device.  The hand-written kernels (SparseConvFn) take Cin in {3, 128} -> 128 at kernel size 3, the shapes MEConvExp uses."""
-    K, Cin, Cout = W.shape
-    if K == 1:   # kernel_size = 1: every voxel is its own only neighbour
-        return X[:M_out] @ W[0]
-    if K == 27 and Cout == 128 and Cin in (3, 128):
-        return SparseConvFn.apply(X, W, nbr, ld, M_out)
-    Y = torch.zeros((M_out, Cout), dtype=X.dtype, device=X.device)
-    for k in range(K):
-        nb = nbr[k, :M_out].long()
-        o = torch.nonzero(nb >= 0).reshape(-1)
-        if o.numel():
-            Y = Y.index_add(0, o, X.index_select(0, nb[o]) @ W[k])
-    return Y
+    """MinkowskiConvolution for any channel widths and kernel sizes (the reference's UNUSED models, models/MEConv.py:25-39,102-130: 1 -> 128,
+    128 -> 64 -> 32 -> 16, kernel-size-1 convolutions): hand-written HIP kernels (conv_any.hip) behind the same Function as the hot shapes."""
+    fn = SparseConvTrueFn if _TRUE_SECOND_ORDER else SparseConvFn
+    return fn.apply(X, W, nbr, ld, M_out)
+
+
+def avg_pool_torch(X, kids, M_out):
+    """MinkowskiAvgPooling(2, 2) as differentiable torch ops (true-second-order mode only; otherwise AvgPoolFn's HIP kernels)."""
+    s = torch.zeros((M_out, X.shape[1]), dtype=X.dtype, device=X.device)
+    n = torch.zeros((M_out, 1), dtype=X.dtype, device=X.device)
+    for k in range(kids.shape[0]):
+        kk = kids[k, :M_out].long()
+        have = (kk >= 0)[:, None]
+        s = s + torch.where(have, X[kk.clamp(min=0)], torch.zeros((), dtype=X.dtype, device=X.device))
+        n = n + have.to(X.dtype)
+    return s / n.clamp(min=1)
 
 
 class AvgPoolFn(Function):

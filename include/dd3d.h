@@ -196,6 +196,24 @@ int dd3d_conv128_bwd_weight_clouds(const float* X, const float* dY, const int32_
                                    int B, const int32_t* group_row_off, int G, float* dW, int32_t* err_dev, void* ws, int64_t ws_bytes,
                                    void* stream);
 
+/* Sparse convolution for ANY channel widths 1 <= Cin, Cout <= dd3d_conv_any_max_channels() (128) and any K >= 1: the general-purpose
+ * siblings of the three entry points above, for the shapes that only the reference's unused model variants name (models/MEConv.py:25-39,
+ * 102-130: 1 -> 128, 128 -> 64 -> 32 -> 16 at kernel size 3; 16 -> 1 and 128 -> 128 at kernel size 1) and for research variants of the network.
+ * Exact-fp32 MFMA on zero-padded 32-wide channel blocks, deterministic.  W is [K,Cin,Cout].  nbr == NULL is allowed for K == 1 only and means
+ * "every row is its own neighbour" (a kernel_size = 1 convolution).  M / M_out may be a bound when m_dev is given.
+ *   fwd:        Y[o]   = sum_k X[nbr[k][o]] . W[k]
+ *   bwd_data:   dX[i]  = sum_k dY[nbr[K-1-k][i]] . W[k]^T   (stride-1 convolution over one coordinate set, odd kernel: K odd)
+ *   bwd_weight: dW[k]  = sum_o X[nbr[k][o]]^T dY[o]          (ONE group; chunk partials in ws, added in chunk order)
+ * replaces: ME.MinkowskiConvolution forward / backward (ConvolutionForwardGPU / ConvolutionBackwardGPU) for models/MEConv.py:25,32,39,102,109,116,130 */
+int dd3d_conv_any_max_channels(void);
+int dd3d_conv_any_fwd(const float* X, int64_t M_in, int Cin, const float* W, int Cout, const int32_t* nbr, int64_t ld, int K, int64_t M_out,
+                      const int32_t* m_dev, float* Y, void* stream);
+int dd3d_conv_any_bwd_data(const float* dY, int64_t M, const int32_t* m_dev, int Cout, const float* W, int Cin, const int32_t* nbr, int64_t ld,
+                           int K, float* dX, void* stream);
+int64_t dd3d_conv_any_bwd_weight_ws_bytes(int K, int Cin, int Cout);
+int dd3d_conv_any_bwd_weight(const float* X, int Cin, const float* dY, int Cout, const int32_t* nbr, int64_t ld, int K, int64_t M_out,
+                             const int32_t* m_dev, float* dW, void* ws, int64_t ws_bytes, void* stream);
+
 /* Wt[k][co][ci] = W[k][ci][co] */
 int dd3d_transpose_kernel(const float* W, int K, int Cin, int Cout, float* Wt, void* stream);
 

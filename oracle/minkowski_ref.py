@@ -183,6 +183,39 @@ def voxel_csr(inv: torch.Tensor, M: int):
 # feature ops as autograd Functions with OPAQUE backward (no_grad), like ME's native ones
 # --------------------------------------------------------------------------------------
 
+# The checker of the product's true-second-order research mode (dd3d_amd.ops.true_second_order; SURVEY.md section 8f row 4 -- NOT the
+# reference's semantics): inside ``true_second_order()`` the modules below compute with plain differentiable torch ops instead of the
+# opaque Functions, so torch autograd differentiates every sparse op twice.  Same forward values.
+_TRUE_SECOND_ORDER = False
+
+
+class true_second_order:
+    def __enter__(self):
+        global _TRUE_SECOND_ORDER
+        self.prev, _TRUE_SECOND_ORDER = _TRUE_SECOND_ORDER, True
+        return self
+
+    def __exit__(self, *exc):
+        global _TRUE_SECOND_ORDER
+        _TRUE_SECOND_ORDER = self.prev
+
+
+def _conv_plain(X, W, nbr):
+    Y = torch.zeros(nbr.shape[1], W.shape[2], dtype=X.dtype)
+    for k in range(nbr.shape[0]):
+        o = torch.nonzero(nbr[k] >= 0).reshape(-1)
+        if o.numel():
+            Y = Y.index_add(0, o, X[nbr[k][o]] @ W[k])
+    return Y
+
+
+def _inorm_plain(X, bidx, B):
+    cnt = torch.bincount(bidx, minlength=B).to(X.dtype).clamp_(min=1)[:, None]
+    seg = lambda t: torch.zeros((B, t.shape[1]), dtype=t.dtype).index_add(0, bidx, t)
+    cen = X - (seg(X) / cnt)[bidx]
+    return cen * (1.0 / torch.sqrt(seg(cen * cen) / cnt + 1e-8))[bidx]
+
+
 
 def _seg_sum(x: torch.Tensor, idx: torch.Tensor, n: int) -> torch.Tensor:
     out = torch.zeros((n,) + tuple(x.shape[1:]), dtype=x.dtype)
@@ -390,9 +423,10 @@ class MinkowskiConvolution(nn.Module):
         ts = x.tensor_stride
         if self.kernel_volume == 1:
             nbr = torch.arange(x.F.shape[0], dtype=torch.int64)[None]
-            return SparseTensor(SparseConvFn.apply(x.F, self.kernel[None], nbr), x.C, ts, x.coordinate_manager)
+            conv = _conv_plain if _TRUE_SECOND_ORDER else SparseConvFn.apply
+            return SparseTensor(conv(x.F, self.kernel[None], nbr), x.C, ts, x.coordinate_manager)
         nbr = x.coordinate_manager.get_kernel_map(ts, ts, self.kernel_size)
-        Y = SparseConvFn.apply(x.F, self.kernel, nbr)
+        Y = _conv_plain(x.F, self.kernel, nbr) if _TRUE_SECOND_ORDER else SparseConvFn.apply(x.F, self.kernel, nbr)
         return SparseTensor(Y, x.C, ts, x.coordinate_manager)
 
     def __repr__(self):
@@ -410,7 +444,7 @@ class MinkowskiInstanceNorm(nn.Module):
     def forward(self, x: SparseTensor):
         b = x.C[:, 0].to(torch.int64)
         B = int(b.max().item()) + 1 if b.numel() else 0
-        out = InstanceNormFn.apply(x.F, b, B)
+        out = _inorm_plain(x.F, b, B) if _TRUE_SECOND_ORDER else InstanceNormFn.apply(x.F, b, B)
         out = out * self.weight + self.bias  # torch-native, like ME
         return SparseTensor(out, x.C, x.tensor_stride, x.coordinate_manager)
 
@@ -492,6 +526,10 @@ class MinkowskiMaxPooling(nn.Module):
             # the forced row must be a child of the pooled voxel: a branch the pooling window really has
             assert bool(((kids.t()[:, :, None] == arg[:, None, :]).any(1)).all()), "forced arg-max row is not a child of its pooled voxel"
             return SparseTensor(ForcedReluPoolFn.apply(x.F, arg, mask), Cout, ts * self.stride, cm)
+        if _TRUE_SECOND_ORDER:   # the winners as MaxPoolFn finds them, the values through a differentiable gather
+            with torch.no_grad():
+                _, arg = MaxPoolFn.apply(x.F.detach(), kids)
+            return SparseTensor(x.F.gather(0, arg), Cout, ts * self.stride, cm)
         out, _ = MaxPoolFn.apply(x.F, kids)
         return SparseTensor(out, Cout, ts * self.stride, cm)
 

@@ -153,6 +153,41 @@ def test_meconvexp_step_vs_oracle_midsize(metric):
             assert rel_err(a, b) < 1e-4
 
 
+def test_true_second_order_mode_vs_oracle():
+    """The true-second-order research mode (NOT the reference's semantics): inside ``ops.true_second_order()``
+    the matching loss is differentiated through every sparse op twice.  Same loss as the default mode (the forward is the same), the xyz
+    gradient equals plain fp64 torch autograd over the restated ops (``oracle.minkowski_ref.true_second_order``) -- and differs from the
+    MinkowskiEngine-faithful gradient, which is what makes the mode worth a name."""
+    from oracle import minkowski_ref as ME
+    from dd3d_amd import ops
+    from dd3d_amd.models.MEConv import MEConvExp
+    net = _load(MEConvExp, R.MEConvExp, False)
+    onet = R.MEConvExp(in_channel=3, out_channel=10)
+    onet.load_state_dict(det_state_dict(onet, "net.MEConvExp"))
+    onet = onet.double().train()
+    reals = [stroke_digits(6, seed=400 + c) for c in range(2)]
+    res = {}
+    for mode in ("me", "true"):
+        d, batches = _distiller(net, reals, 2, "modmse", 2)
+        osyn = d.image_syn.detach().cpu().double().clone()
+        R.clamp_synthetic_(osyn)
+        osyn.requires_grad_()
+        if mode == "true":
+            with ME.true_second_order():
+                ref = R.matching_step(onet, osyn, reals, 2, "modmse", False)
+            with ops.true_second_order():
+                loss = d.outer_step(real_batches=batches, apply_update=False)
+        else:
+            ref = R.matching_step(onet, osyn, reals, 2, "modmse", False)
+            loss = d.outer_step(real_batches=batches, apply_update=False)
+        assert loss.item() == pytest.approx(ref["loss"].item(), rel=1e-4)
+        assert rel_err(d.last["grad"], ref["grad"]) < 1e-4
+        res[mode] = (loss.item(), d.last["grad"].clone())
+    assert res["me"][0] == pytest.approx(res["true"][0], rel=1e-6)
+    assert rel_err(res["me"][1], res["true"][1]) > 1e-3
+    assert not ops.true_second_order_enabled()
+
+
 def test_inner_network_update_vs_oracle_and_class_shards():
     """The inner-loop network update (no reference behaviour: mnist_distill.py:262 declares the loop and never runs it) follows the loop's
     per-class synthetic forward (:351-355).  Checked against the fp64 oracle restating the same thing, and: the parameter gradients of two

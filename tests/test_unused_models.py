@@ -96,30 +96,115 @@ def test_average_pooling_kernels_vs_oracle(case, C):
     assert rel_err(x.grad, xr.grad) < 1e-6
 
 
-@pytest.mark.gpu
-def test_generic_convolution_path_vs_oracle():
-    """Channel counts and kernel sizes that only the unused MEConv stack uses (1 -> 128 at kernel 3 runs on the library-GEMM path,
-    32 -> 16 too, 16 -> 1 at kernel size 1)."""
-    from dd3d_amd.ops import sparse_conv_any
+def _conv_maps(B, pts, extent, seed):
     from dd3d_amd.sparse import CoordinateManager
-    coords = _coords(B=3, pts=150, extent=7, seed=5)
+    coords = _coords(B=B, pts=pts, extent=extent, seed=seed)
     cm = CoordinateManager(coords.to(DEV), None)
     nbr, ld = cm.kernel_map(1, 1, 3)
     cm.sync()
     M = cm.num_rows(1)
     ref_nbr = ME.kernel_map(cm.coordinates(1).cpu(), cm.coordinates(1).cpu(), 3, 1)
+    return nbr, ld, M, ref_nbr
+
+
+ANY_SHAPES = ((27, 1, 128), (27, 128, 64), (27, 64, 32), (27, 32, 16), (1, 16, 1), (1, 128, 128), (27, 5, 7), (27, 100, 33))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("maps", [dict(B=3, pts=150, extent=7, seed=5), dict(B=30, pts=900, extent=24, seed=9)])
+def test_generic_convolution_kernels_vs_oracle(maps):
+    """Channel counts and kernel sizes that only the unused MEConv / MEConvImage stacks use (models/MEConv.py:25-39,102-130: 1 -> 128,
+    128 -> 64 -> 32 -> 16 at kernel size 3, 16 -> 1 and 128 -> 128 at kernel size 1) plus two odd ones: forward, input gradient and kernel
+    gradient of the hand-written kernels (conv_any.hip, fp32 MFMA) against the fp64 restatement."""
+    from dd3d_amd.ops import sparse_conv_any
+    nbr, ld, M, ref_nbr = _conv_maps(**maps)
     g = torch.Generator().manual_seed(6)
-    for K, Cin, Cout in ((27, 1, 128), (27, 32, 16), (1, 16, 1)):
+    for K, Cin, Cout in ANY_SHAPES:
         X, W = torch.randn(M, Cin, generator=g), torch.randn(K, Cin, Cout, generator=g) * 0.2
         x, w = X.to(DEV).requires_grad_(), W.to(DEV).requires_grad_()
         xr, wr = X.double().requires_grad_(), W.double().requires_grad_()
-        Y = sparse_conv_any(x, w, nbr, ld, M)
+        Y = sparse_conv_any(x, w, nbr if K == 27 else None, ld if K == 27 else 0, M)
         Yr = ME.SparseConvFn.apply(xr, wr, ref_nbr if K == 27 else torch.arange(M)[None])
-        assert rel_err(Y, Yr) < 2e-5
+        assert rel_err(Y, Yr) < 1e-5, (K, Cin, Cout)
         gy = torch.randn(M, Cout, generator=g, dtype=torch.float64)
         (Yr * gy).sum().backward()
         (Y * gy.float().to(DEV)).sum().backward()
-        assert rel_err(x.grad, xr.grad) < 2e-5 and rel_err(w.grad, wr.grad) < 2e-5
+        assert rel_err(x.grad, xr.grad) < 1e-5 and rel_err(w.grad, wr.grad) < 1e-5, (K, Cin, Cout)
+
+
+@pytest.mark.gpu
+def test_generic_convolution_bound_sized_launch_is_bitwise_the_exact_one():
+    """M as a bound with the true count on the device (what lets a caller capture the launch): rows below the count carry the same bits as
+    the exact launch, rows beyond it are not touched, the kernel gradient is the same bits (its row chunks follow the true count); and
+    the argument errors of the C-ABI."""
+    from dd3d_amd import _lib as L
+    nbr, ld, M, _ = _conv_maps(B=6, pts=300, extent=10, seed=12)
+    K, Cin, Cout, bound = 27, 64, 32, M + 777
+    g = torch.Generator().manual_seed(3)
+    X = torch.randn(bound, Cin, generator=g).to(DEV)
+    W = (torch.randn(K, Cin, Cout, generator=g) * 0.2).to(DEV)
+    gY = torch.randn(bound, Cout, generator=g).to(DEV)
+    nbr_b = torch.full((K, bound), -1, dtype=torch.int32, device=DEV)
+    nbr_b[:, :M] = nbr[:, :M]
+    nbr_b[:, M:] = 0                                         # stale entries beyond the count must not be read as neighbours
+    m_dev = torch.tensor([M], dtype=torch.int32, device=DEV)
+    ws = torch.empty(int(L.lib.dd3d_conv_any_bwd_weight_ws_bytes(K, Cin, Cout)), dtype=torch.uint8, device=DEV)
+    st = L.stream()
+
+    def run(Mx, md, table, ldx):
+        Y = torch.full((bound, Cout), 7.0, device=DEV)
+        dX = torch.full((bound, Cin), 7.0, device=DEV)
+        dW = torch.empty((K, Cin, Cout), device=DEV)
+        L.call("dd3d_conv_any_fwd", L.ptr(X), bound, Cin, L.ptr(W), Cout, L.ptr(table), ldx, K, Mx, L.ptr(md), L.ptr(Y), st)
+        L.call("dd3d_conv_any_bwd_data", L.ptr(gY), Mx, L.ptr(md), Cout, L.ptr(W), Cin, L.ptr(table), ldx, K, L.ptr(dX), st)
+        L.call("dd3d_conv_any_bwd_weight", L.ptr(X), Cin, L.ptr(gY), Cout, L.ptr(table), ldx, K, Mx, L.ptr(md), L.ptr(dW), L.ptr(ws), ws.numel(), st)
+        return Y, dX, dW
+
+    exact, bounded = run(M, None, nbr, ld), run(bound, m_dev, nbr_b, bound)
+    for a, b in zip(exact, bounded):
+        assert torch.equal(a, b)
+    assert bool((bounded[0][M:] == 7.0).all()) and bool((bounded[1][M:] == 7.0).all())
+    assert L.lib.dd3d_conv_any_max_channels() == 128
+    Y = torch.empty((M, 200), device=DEV)
+    for args in (("dd3d_conv_any_fwd", L.ptr(X), M, 129, L.ptr(W), Cout, L.ptr(nbr), ld, K, M, None, L.ptr(Y), st),           # too wide
+                 ("dd3d_conv_any_fwd", L.ptr(X), M, Cin, L.ptr(W), Cout, None, 0, K, M, None, L.ptr(Y), st),                    # no table but K > 1
+                 ("dd3d_conv_any_bwd_data", L.ptr(gY), M, None, Cout, L.ptr(W), Cin, L.ptr(nbr), ld, 8, L.ptr(Y), st)):         # even K has no mirror
+        with pytest.raises(RuntimeError):
+            L.call(*args)
+
+
+def _plain_conv(X, W, nbr):
+    Y = torch.zeros(nbr.shape[1], W.shape[2], dtype=X.dtype)
+    for k in range(nbr.shape[0]):
+        o = torch.nonzero(nbr[k] >= 0).reshape(-1)
+        if o.numel():
+            Y = Y.index_add(0, o, X[nbr[k][o]] @ W[k])
+    return Y
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Cin,Cout", [(128, 128), (3, 128), (32, 16)])
+def test_convolution_gradient_of_gradient_vs_fp64(Cin, Cout):
+    """SparseConvTrueFn (the true-second-order research mode): the backward of the convolution is itself
+    differentiable.  The gradient of a function of (dL/dX, dL/dW) with respect to X and W against plain fp64 torch autograd -- for the
+    hot shapes (their own kernels) and a generic one."""
+    from dd3d_amd.ops import SparseConvTrueFn
+    nbr, ld, M, ref_nbr = _conv_maps(B=4, pts=200, extent=8, seed=21)
+    g = torch.Generator().manual_seed(8)
+    X, W = torch.randn(M, Cin, generator=g), torch.randn(27, Cin, Cout, generator=g) * 0.1
+    r1, r2 = torch.randn(M, Cin, generator=g, dtype=torch.float64), torch.randn(27, Cin, Cout, generator=g, dtype=torch.float64)
+
+    def second(x, w, conv, r1, r2):
+        y = conv(x, w)
+        gx, gw = torch.autograd.grad(0.5 * (y * y).sum(), (x, w), create_graph=True)
+        return (gx, gw) + torch.autograd.grad((gx * r1).sum() + (gw * r2).sum() + (gx * gx).sum(), (x, w))
+
+    x, w = X.to(DEV).requires_grad_(), W.to(DEV).requires_grad_()
+    xr, wr = X.double().requires_grad_(), W.double().requires_grad_()
+    got = second(x, w, lambda a, b: SparseConvTrueFn.apply(a, b, nbr, ld, M), r1.float().to(DEV), r2.float().to(DEV))
+    ref = second(xr, wr, lambda a, b: _plain_conv(a, b, ref_nbr), r1, r2)
+    for a, b in zip(got, ref):
+        assert rel_err(a, b) < 2e-5
 
 
 @pytest.mark.gpu
