@@ -350,7 +350,8 @@ __global__ void k_cloud_offsets(const int* __restrict__ pool_off, const int* __r
             tot += x;
         }
         int carry = s_carry;
-        if (b < B) pt_off[b] = point_base + carry + wbase + incl - v;
+        // (clamped like the total below: behind an overfull batch every later cloud is empty, none starts outside the caller's buffers)
+        if (b < B) pt_off[b] = (int)min((int64_t)(point_base + carry + wbase + incl - v), bound);
         __syncthreads();
         if (threadIdx.x == 0) s_carry = carry + tot;
         __syncthreads();
@@ -454,7 +455,9 @@ __global__ __launch_bounds__(128) void k_assemble_batch(float* __restrict__ xyz,
     const bool ok = id >= 0 && id < n_pool;
     const int cnt = ok ? min(pool_off[id + 1] - pool_off[id], cap) : 0;
     if (tid == 0) {
-        pt_off[b] = start;
+        // clamped like the total: in a batch that exceeds the bound (flagged below) the clouds behind it come out empty or cut short, and no
+        // offset points outside the buffers that every later kernel sizes by the bound
+        pt_off[b] = (int)min((int64_t)start, bound);
         if (!ok) atomicOr(err, 4);  // sampled index outside the pool: the cloud comes out empty
         if (b == B - 1) {
             int total = start + cnt;

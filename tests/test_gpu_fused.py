@@ -145,6 +145,8 @@ def test_gather_clouds_equals_collate():
         L.call("dd3d_gather_clouds", L.ptr(xyz), L.ptr(off), 40, L.ptr(ids), 6, cap, 64, 0, 0, 1.0, L.ptr(coords), L.ptr(feats), L.ptr(pt_off), L.ptr(n),
                L.ptr(err), L.stream())
         assert int(err.item()) == 4 and int(n.item()) == 64
+        # ... and no cloud STARTS beyond the bound either (the map builder reads coords[pt_off[b] ... pt_off[b + 1]) of buffers sized by it)
+        assert int(pt_off.max()) == 64 and bool((pt_off[1:] >= pt_off[:-1]).all())
         err.zero_()
         bad = torch.tensor([1, 40, -1, 2, 2, 2], dtype=torch.int32, device=DEV)
         L.call("dd3d_gather_clouds", L.ptr(xyz), L.ptr(off), 40, L.ptr(bad), 6, cap, bound, 0, 0, 1.0, L.ptr(coords), L.ptr(feats), L.ptr(pt_off), L.ptr(n),
