@@ -355,6 +355,7 @@ def main():
             torch.cuda.synchronize()
             out["dropin_ms_per_step"] = (time.perf_counter() - t0) / 3 * 1e3
             out["cpu_baseline"] = cpu_baseline(images_all, indices_class, net, syn, args)
+            out["cpu_baseline_torch"] = cpu_baseline_torch(images_all, indices_class, net, syn, args)
             out["cpu_baseline_pytorch"] = cpu_baseline_pytorch(images_all, indices_class, args)
         print(json.dumps(out), flush=True)
     if torch.distributed.is_initialized():
@@ -362,6 +363,33 @@ def main():
 
 
 def cpu_baseline(images_all, indices_class, net, syn, args):
+    """The oracle's C++/OpenMP leg (oracle/cpu/dd3d_cpu.cpp: hash-table maps, register-blocked gather convolutions, the second-order pass
+    written out by hand; fp32, every host thread OpenMP gives it) on the SAME workload -- all 10 classes, 256 real clouds each, the
+    reference's per-class loop, clamp and SGD with momentum on the host: one untimed warm-up step, then a bounded number of timed steps."""
+    import numpy as np
+    from oracle import cpu_leg as CL
+    cnet = CL.Network(net, np.float32)
+    rng = np.random.RandomState(1234)
+    x = syn.detach().cpu().double().numpy().copy()
+    mom = np.zeros_like(x)
+    imgs = images_all.cpu().numpy()
+    nsteps, t = 12, 0.0
+    for it in range(nsteps + 1):
+        reals = [imgs[rng.permutation(indices_class[c])[:REAL_PER_CLASS]] for c in range(NUM_CLASSES)]
+        t0 = time.perf_counter()
+        np.clip(x, 0.0, 27.0, out=x)          # mnist_distill.py:311-317
+        x[:, :, 0] = 0.0
+        g = CL.matching_step(cnet, x, reals, args.ipc, args.metric_name, num_points=NUM_POINTS)["grad"]
+        mom = 0.5 * mom + g                    # torch.optim.SGD(lr=0.1, momentum=0.5), mnist_distill.py:268
+        x -= 0.1 * mom
+        if it > 0:
+            t += time.perf_counter() - t0
+    return {"value": nsteps / t, "unit": "steps/s", "cores": int(CL.lib().dd3d_cpu_max_threads()), "kind": "port",
+            "implementation": "C++/OpenMP (oracle/cpu/dd3d_cpu.cpp), fp32",
+            "sample": f"{nsteps} full steps of the same workload after 1 warm-up step, {t:.1f} s of CPU work"}
+
+
+def cpu_baseline_torch(images_all, indices_class, net, syn, args):
     """The CPU oracle (torch restatement of the reference's step over the MinkowskiEngine restatement, oracle/) on the host cores:
     the SAME workload (all 10 classes), one untimed warm-up step then 8 timed steps (about 10-30 s of CPU work)."""
     from oracle import ref_model as R
@@ -372,7 +400,7 @@ def cpu_baseline(images_all, indices_class, net, syn, args):
     osyn = syn.clone()
     osyn.requires_grad_()
     opt = torch.optim.SGD([osyn], lr=0.1, momentum=0.5)
-    nsteps, t = 8, 0.0
+    nsteps, t = 6, 0.0
     for it in range(nsteps + 1):
         reals = [images_all[rng.permutation(indices_class[c])[:REAL_PER_CLASS]] for c in range(NUM_CLASSES)]
         osyn.requires_grad_(False)
@@ -383,6 +411,7 @@ def cpu_baseline(images_all, indices_class, net, syn, args):
         if it > 0:
             t += time.perf_counter() - t0
     return {"value": nsteps / t, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "implementation": "torch (oracle/ref_model.py over oracle/minkowski_ref.py), fp32",
             "sample": f"{nsteps} full steps of the same workload after 1 warm-up step, {t:.1f} s of CPU work"}
 
 

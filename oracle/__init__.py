@@ -13,4 +13,8 @@ semantics restated in ``oracle/minkowski_ref.py`` are **parity unpinned**: the
 library is a third-party native dependency (``environment.yml:278``) that is
 absent from /root/reference and not installable offline, and the reference has
 no tests or fixtures at that boundary.
+
+Two legs that share no code and are tested against each other (``tests/test_cpu_leg.py``): the torch restatement
+(``minkowski_ref.py`` + ``ref_model.py``, what the golden fixtures pin) and a C++/OpenMP one (``cpu/dd3d_cpu.cpp`` behind
+``cpu_leg.py``; built by ``__graft_entry__.build()`` / ``make -C oracle/cpu``).
 """
