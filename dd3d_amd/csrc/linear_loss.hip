@@ -394,6 +394,23 @@ __global__ __launch_bounds__(256) void k_cls_head(const float* __restrict__ part
     }
 }
 
+// per_class[g] = (a[g] + b[g]) + c[g] (b, c nullable) and total = sum_g per_class[g]: the three partial matching losses of a step and their
+// sum in ONE launch (torch: two additions and a reduction, three dependent graph nodes at the very end of a step).  One wave; lane l adds
+// groups l, l + 64, ... in order, then the fixed shuffle tree of wave_sum: deterministic.
+__global__ void k_loss_total(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c, int G, float* __restrict__ per_class,
+                             float* __restrict__ total) {
+    float s = 0.f;
+    for (int g = threadIdx.x; g < G; g += 64) {
+        float v = a[g];
+        if (b) v += b[g];
+        if (c) v += c[g];
+        if (per_class) per_class[g] = v;
+        s += v;
+    }
+    s = wave_sum(s);
+    if (threadIdx.x == 0 && total) *total = s;
+}
+
 // second order: dlogits = (softmax(z) - onehot)/B_g ; given u = dL/d(dlogits) -> dz = p * (u - <p,u>) / B_g
 __global__ void k_softmax_ce_bwd2(const float* __restrict__ prob, const float* __restrict__ u, const float* __restrict__ u_group /*[G][J] or null*/,
                                   const int* __restrict__ group_cloud_off, int G, int J, float* __restrict__ dz) {
@@ -835,6 +852,14 @@ DD3D_API int dd3d_softmax_ce(const float* logits, const int32_t* labels, const i
 DD3D_API int dd3d_group_sum_rows(const float* v, const int32_t* group_cloud_off, int G, int J, float* out, void* stream) {
     if (G <= 0 || J <= 0 || !v || !group_cloud_off || !out) return DD3D_EARG;
     k_group_sum_rows<<<dim3(G * J), 64, 0, (hipStream_t)stream>>>(v, group_cloud_off, G, J, out);
+    DD3D_CHECK_LAUNCH();
+    return 0;
+}
+
+// per_class[G] (nullable) = a + b + c elementwise (b, c nullable), *total (nullable) = their sum over the groups; one launch.
+DD3D_API int dd3d_loss_total(const float* a, const float* b, const float* c, int G, float* per_class, float* total, void* stream) {
+    if (G < 0 || (G > 0 && !a)) return DD3D_EARG;
+    k_loss_total<<<1, 64, 0, (hipStream_t)stream>>>(a, b, c, G, per_class, total);
     DD3D_CHECK_LAUNCH();
     return 0;
 }

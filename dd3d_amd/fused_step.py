@@ -1146,6 +1146,7 @@ class FusedDistiller:
         # layers together and keeps the joint launch.
         main, side = torch.cuda.current_stream(dev), self.stream_side
         diff, const = [1, 4, 6, 7], [0, 2, 3, 5]
+        grad = total = None   # set by the branch that has already enqueued the update / the one-launch loss sum
         if self.split:
             # second sharding level: this rank's PARTIAL real gradients (already weighted n_part / n) are summed over the ranks that share
             # the classes; every stream joins first (a graph capture may end here)
@@ -1175,10 +1176,15 @@ class FusedDistiller:
                 loss_b, _ = grouped_match_loss([gw_syn[i] for i in const], [gw_real[i] for i in const], self.dist_opt, G, [False] * 4)
             main.wait_event(ev_h)
             dfeats = p.backward_from_conv(hP0, d1[0])
+            # the update needs the point gradient only: it goes into the queue BEFORE the join with the loss terms of the constant entries
+            # (which end last: they wait for the first layer's kernel gradient), and the per-class and total loss are ONE launch behind the
+            # join instead of two additions and a reduction -- two dependent graph nodes less at the very end of a step
+            grad = self._scatter_update(dfeats, G, ipc, npts)
             main.wait_stream(side)
             if not static:
                 loss_b.record_stream(main)
-            loss_g = loss_a1 + loss_a2 + loss_b
+            loss_g, total = torch.empty(G, dtype=_F32, device=dev), torch.empty((), dtype=_F32, device=dev)
+            L.call("dd3d_loss_total", L.ptr(loss_a1), L.ptr(loss_a2), L.ptr(loss_b), G, L.ptr(loss_g), L.ptr(total), L.stream())
         elif self.dist_opt in ("ours", "modmse", "mse") and os.environ.get("DD3D_LOSS_SPLIT", "1") != "0":
             main.wait_event(p.ev_cls)
             loss_a, d4 = grouped_match_loss([gw_syn[i] for i in diff], [gw_real[i] for i in diff], self.dist_opt, G, [True] * 4)
@@ -1196,15 +1202,22 @@ class FusedDistiller:
             need = [i in diff for i in range(8)]
             loss_g, d = grouped_match_loss(gw_syn, gw_real, self.dist_opt, G, need)
             dfeats = p.backward_to_points(d[1], d[4], d[6], d[7], ipc)
+        if grad is None:
+            grad = self._scatter_update(dfeats, G, ipc, npts)
+        Bs = G * ipc
+        self.last = {"per_class": loss_g, "grad": grad, "gw_real": _GradList(gw_real, net.dense_extent, extent),
+                     "gw_syn": _GradList(gw_syn, net.dense_extent, extent), "logits": (p.logits[Bs:], p.logits[:Bs]),
+                     "conv1_maps": [(p.maps[4], p.M[1], p.cnt[1])], "passes": (p,)}
+        return total if total is not None else loss_g.sum()
+
+    def _scatter_update(self, dfeats, G, ipc, npts):
+        """The point gradient of the owned clouds into a tensor shaped like image_syn, and (unless the caller asked for the gradient only)
+        the SGD step with momentum, on the current stream.  Returns the gradient tensor."""
         grad = torch.empty_like(self.image_syn)
         fused_tail = self._apply_update and self.image_syn.shape[1] == npts
         if not fused_tail:
             grad.zero_()
             grad[self.syn_rows] = dfeats.reshape(G * ipc, npts, 3)
-        Bs = G * ipc
-        self.last = {"per_class": loss_g, "grad": grad, "gw_real": _GradList(gw_real, net.dense_extent, extent),
-                     "gw_syn": _GradList(gw_syn, net.dense_extent, extent), "logits": (p.logits[Bs:], p.logits[:Bs]),
-                     "conv1_maps": [(p.maps[4], p.M[1], p.cnt[1])], "passes": (p,)}
         if fused_tail:
             # gradient scatter + SGD in one launch; momentum_buf starts at zero, so the first step needs no special case (0.5 * 0 + g == g)
             L.call("dd3d_sgd_scatter", L.ptr(self.image_syn), L.ptr(self.momentum_buf), L.ptr(dfeats), L.ptr(self.dest_cloud),
@@ -1212,7 +1225,7 @@ class FusedDistiller:
         elif self._apply_update:
             L.call("dd3d_sgd_momentum_clamp", L.ptr(self.image_syn), L.ptr(grad), L.ptr(self.momentum_buf), self.image_syn.numel(), self.lr,
                    self.momentum, 0, 0, 0.0, 27.0, L.stream())
-        return loss_g.sum()
+        return grad
 
     def _static_body(self, parity=0):
         """_static_body_gen with the exchange of a split real batch (if any) done in line (the eager first step)."""

@@ -337,6 +337,11 @@ int dd3d_classifier_layout(const float* in, int G, int J, int C, int S, int inve
 int dd3d_softmax_ce(const float* logits, const int32_t* labels, const int32_t* cloud_group, const int32_t* group_cloud_off, int G, int B, int J,
                     float* prob, float* dlogits, float* cloud_loss, float* loss_g, void* stream);
 int dd3d_group_sum_rows(const float* v, const int32_t* group_cloud_off, int G, int J, float* out, void* stream);
+
+/* per_class[G] = a + b + c (b, c nullable; the partial matching losses of a step, which are computed on different streams) and
+ * *total = the sum over the groups, in one launch; per_class / total nullable.  Deterministic.
+ * replaces: the running `loss +=` over the classes, mnist_distill.py:361 */
+int dd3d_loss_total(const float* a, const float* b, const float* c, int G, float* per_class, float* total, void* stream);
 int dd3d_softmax_ce_bwd2(const float* prob, const float* u, const float* u_group /* [G,J] added to every cloud's u, nullable */,
                          const int32_t* group_cloud_off, int G, int J, int max_clouds_per_group, float* dz, void* stream);
 

@@ -457,6 +457,23 @@ def test_sparse_linear_bwd_w_layouts_groups_and_long_lists(B, J, gco):
     assert rel_err(outs["param"], ref) < 2e-5
 
 
+def test_loss_total_is_the_two_additions_and_the_sum():
+    """dd3d_loss_total: per_class = (a + b) + c with torch's own bits, total = their sum (fp32 rounding of another order), nullable terms and
+    outputs, more groups than lanes."""
+    from dd3d_amd import _lib as L
+    g = torch.Generator().manual_seed(2)
+    for G in (1, 10, 40, 200):
+        a, b, c = (torch.rand(G, generator=g).to(dev()) * 1e3 for _ in range(3))
+        per, tot = torch.empty(G, device=dev()), torch.empty((), device=dev())
+        L.call("dd3d_loss_total", L.ptr(a), L.ptr(b), L.ptr(c), G, L.ptr(per), L.ptr(tot), L.stream())
+        assert torch.equal(per, (a + b) + c)
+        assert tot.item() == pytest.approx(per.double().sum().item(), rel=1e-6)
+        L.call("dd3d_loss_total", L.ptr(a), None, L.ptr(c), G, None, L.ptr(tot), L.stream())
+        assert tot.item() == pytest.approx((a + c).double().sum().item(), rel=1e-6)
+        L.call("dd3d_loss_total", L.ptr(a), None, None, G, L.ptr(per), None, L.stream())
+        assert torch.equal(per, a)
+
+
 def test_true_divide_is_the_host_division_on_the_device():
     """coordinates / quantization_size: the reference divides host tensors (a correctly rounded fp32 division, models/MEConv.py:262).  On the
     device ``tensor / python_scalar`` multiplies by the rounded reciprocal -- different bits for a voxel size like 0.05, different VOXELS for
