@@ -661,6 +661,119 @@ __global__ __launch_bounds__(256) void k_gd_bwd(const GPlan p, const float4* __r
     }
 }
 
+// k_gd_stats + k_gd_finalize (+ k_gd_bwd) in ONE launch for SMALL lists -- every segment row-contiguous with at most GD_SMALL_COLS columns and
+// at most GD_SMALL_ROWS rows in all: an instance-norm weight's gradient ([1,128] per class), the loss term that sits alone on the tail of a step.
+// Such a list is three dependent launches of a handful of workgroups each, i.e. ~20 us of dispatch latency for microseconds of work, twice on
+// the critical path of a step.  One workgroup per group walks the rows with EXACTLY the arithmetic of the three kernels (the same per-thread
+// element order, wave sums, four-wave combine, 256-slot pairwise tree, coefficients), so every output has the same bits.
+constexpr int GD_SMALL_ROWS = 8;      // a workgroup walks its rows one after the other: more rows (or longer ones) are faster as three wide launches
+constexpr int GD_SMALL_COLS = 2048;   // (measured: the twelve rows of up to 6272 columns of the classifier's gradients: +58 us per step in one launch)
+__global__ __launch_bounds__(256) void k_gd_small(const GPlan p, float4* __restrict__ stats, float* __restrict__ loss, const float* __restrict__ gl, int bwd) {
+    __shared__ float s_red[4 * 4];
+    __shared__ float s_term[256];
+    __shared__ float4 s_tot[256];
+    const int tid = threadIdx.x, g = blockIdx.x;
+    const int total_rows = p.row_off[p.n];
+    stats += (int64_t)g * (total_rows + 1);
+    s_term[tid] = 0.f;
+    s_tot[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    for (int gr = 0; gr < total_rows; ++gr) {
+        int s = 0;
+        while (s + 1 < p.n && gr >= p.row_off[s + 1]) ++s;
+        const dd3d_gseg sg = p.seg[s];
+        const int row = gr - p.row_off[s];
+        const int64_t goff = (int64_t)g * sg.rows * sg.cols, e1 = sg.cols;
+        const float* a = sg.syn + goff + row * sg.cols;
+        const float* b = sg.real + goff + row * sg.cols;
+        float dot = 0.f, ss = 0.f, rr = 0.f, sq = 0.f;
+        for (int64_t e = tid; e < e1; e += 256 * GD_U) {
+            float x[GD_U], y[GD_U];
+#pragma unroll
+            for (int j = 0; j < GD_U; ++j) {
+                const int64_t ej = e + 256 * j, ec = min(ej, e1 - 1);
+                x[j] = a[ec]; y[j] = b[ec];
+                if (ej >= e1) x[j] = y[j] = 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < GD_U; ++j) {
+                const float d = x[j] - y[j];
+                dot += x[j] * y[j]; ss += x[j] * x[j]; rr += y[j] * y[j]; sq += d * d;
+            }
+        }
+        dot = wave_sum(dot); ss = wave_sum(ss); rr = wave_sum(rr); sq = wave_sum(sq);
+        if ((tid & 63) == 0) {
+            const int w = tid >> 6;
+            s_red[w * 4 + 0] = dot; s_red[w * 4 + 1] = ss; s_red[w * 4 + 2] = rr; s_red[w * 4 + 3] = sq;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float4 st = make_float4(0.f, 0.f, 0.f, 0.f);  // (k_gd_finalize adds the row's one chunk record into zeros)
+            st.x += s_red[0] + s_red[4] + s_red[8] + s_red[12];
+            st.y += s_red[1] + s_red[5] + s_red[9] + s_red[13];
+            st.z += s_red[2] + s_red[6] + s_red[10] + s_red[14];
+            st.w += s_red[3] + s_red[7] + s_red[11] + s_red[15];
+            stats[gr] = st;
+            s_term[gr] = row_term(p.metric, st);
+            s_tot[gr] = st;
+        }
+        __syncthreads();
+    }
+    for (int off = 128; off > 0; off >>= 1) {  // the pairwise tree of k_gd_finalize over the 256 slots (rows beyond total_rows hold zeros)
+        if (tid < off) {
+            s_term[tid] += s_term[tid + off];
+            float4 x = s_tot[tid], y = s_tot[tid + off];
+            s_tot[tid] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        float run = 0.f;
+        float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+        run += s_term[0];
+        tot.x += s_tot[0].x; tot.y += s_tot[0].y; tot.z += s_tot[0].z; tot.w += s_tot[0].w;
+        float L;
+        if (p.metric == 0 || p.metric == 1) L = run;
+        else if (p.metric == 2) L = tot.w;
+        else L = 1.0f - tot.x / (sqrtf(tot.z) * sqrtf(tot.y) + 0.000001f);
+        loss[g] = L;
+        stats[total_rows] = tot;
+    }
+    if (!bwd) return;
+    __syncthreads();  // (workgroup-scope fence: the stats written by thread 0 are read back below)
+    const float up = gl ? gl[0] : 1.0f;
+    const int metric = p.metric;
+    for (int gr = 0; gr < total_rows; ++gr) {
+        int s = 0;
+        while (s + 1 < p.n && gr >= p.row_off[s + 1]) ++s;
+        const dd3d_gseg sg = p.seg[s];
+        if (!sg.dsyn) continue;
+        const int row = gr - p.row_off[s];
+        const int64_t goff = (int64_t)g * sg.rows * sg.cols, e1 = sg.cols;
+        const float* a = sg.syn + goff + row * sg.cols;
+        const float* b = sg.real + goff + row * sg.cols;
+        float* d = sg.dsyn + goff + row * sg.cols;
+        float ca = 0.f, cb = 0.f;
+        if (metric == 0 || metric == 3) {
+            const float4 st = stats[metric == 0 ? gr : total_rows];
+            const float nr = sqrtf(st.z), ns = sqrtf(st.y), den = nr * ns + 0.000001f;
+            ca = -up / den;
+            cb = ns > 0.f ? up * st.x * nr / (ns * den * den) : 0.f;
+        }
+        for (int64_t e = tid; e < e1; e += 256 * GD_U) {
+            float x[GD_U], y[GD_U];
+#pragma unroll
+            for (int j = 0; j < GD_U; ++j) {
+                const int64_t ec = min(e + 256 * j, e1 - 1);
+                x[j] = a[ec]; y[j] = b[ec];
+            }
+#pragma unroll
+            for (int j = 0; j < GD_U; ++j)
+                if (e + 256 * j < e1) d[e + 256 * j] = (metric == 1 || metric == 2) ? 2.0f * up * (x[j] - y[j]) : ca * y[j] + cb * x[j];
+        }
+    }
+}
+
 // SGD with momentum on the synthetic xyz + the clamp of the NEXT iteration's prologue (mnist_distill.py:311-317,369)
 __global__ void k_sgd_clamp(float* __restrict__ x, const float* __restrict__ grad, float* __restrict__ mom, int64_t n, float lr, float momentum,
                             int first_step, int do_clamp, float lo, float hi) {
@@ -872,6 +985,14 @@ DD3D_API int dd3d_softmax_ce_bwd2(const float* prob, const float* u, const float
     return 0;
 }
 
+static bool plan_is_small(const GPlan& p) {
+    static const bool off = getenv("DD3D_GD_SMALL") && !atoi(getenv("DD3D_GD_SMALL"));  // 0: always the three launches (measurements, tests)
+    if (off || p.row_off[p.n] > GD_SMALL_ROWS) return false;
+    for (int s = 0; s < p.n; ++s)
+        if (p.seg[s].colmajor || p.nchunk[s] != 1 || p.seg[s].cols > GD_SMALL_COLS) return false;
+    return true;
+}
+
 DD3D_API int64_t dd3d_match_loss_ws_bytes(const dd3d_gseg* segs, int n, int G) {
     GPlan p;
     if (G <= 0 || build_plan(segs, n, 0, &p)) return -1;
@@ -894,11 +1015,34 @@ DD3D_API int dd3d_match_loss_fwd(const dd3d_gseg* segs, int n, int G, int metric
     if (!loss_dev || !stats_dev || G <= 0 || G > 65535) return DD3D_EARG;
     if (!ws || ws_bytes < dd3d_match_loss_ws_bytes(segs, n, G)) return DD3D_EWS;
     hipStream_t st = (hipStream_t)stream;
+    if (plan_is_small(p)) {  // one launch, the same bits
+        k_gd_small<<<G, 256, 0, st>>>(p, (float4*)stats_dev, loss_dev, nullptr, 0);
+        DD3D_CHECK_LAUNCH();
+        return 0;
+    }
     float4* partial = (float4*)ws;
     k_gd_stats<<<dim3(p.item_off[n], G), 256, 0, st>>>(p, partial);
     k_gd_finalize<<<G, 256, 0, st>>>(p, partial, (float4*)stats_dev, loss_dev);
     DD3D_CHECK_LAUNCH();
     return 0;
+}
+
+// dd3d_match_loss_fwd followed by dd3d_match_loss_bwd (same outputs, bit for bit): ONE launch for small lists (see k_gd_small), the three
+// launches otherwise.
+DD3D_API int dd3d_match_loss_fwd_bwd(const dd3d_gseg* segs, int n, int G, int metric, float* loss_dev, float* stats_dev, const float* gl_dev, void* ws,
+                                     int64_t ws_bytes, void* stream) {
+    GPlan p;
+    int rc = build_plan(segs, n, metric, &p);
+    if (rc) return rc;
+    if (!loss_dev || !stats_dev || G <= 0 || G > 65535) return DD3D_EARG;
+    if (plan_is_small(p)) {
+        k_gd_small<<<G, 256, 0, (hipStream_t)stream>>>(p, (float4*)stats_dev, loss_dev, gl_dev, 1);
+        DD3D_CHECK_LAUNCH();
+        return 0;
+    }
+    rc = dd3d_match_loss_fwd(segs, n, G, metric, loss_dev, stats_dev, ws, ws_bytes, stream);
+    if (rc) return rc;
+    return dd3d_match_loss_bwd(segs, n, G, metric, stats_dev, gl_dev, ws, ws_bytes, stream);
 }
 
 // writes seg[i].dsyn (where non-null) = gl * d loss / d seg[i].syn ; gl_dev may be null (= 1)

@@ -475,9 +475,10 @@ def grouped_match_loss(gw_syn: List[torch.Tensor], gw_real: List[torch.Tensor], 
     stats = _empty((int(L.lib.dd3d_match_loss_stats_floats(segs, n, G)),), dev)
     loss = loss_out if loss_out is not None else _empty((G,), dev)
     ws = L.workspace(int(L.lib.dd3d_match_loss_ws_bytes(segs, n, G)), dev)
-    L.call("dd3d_match_loss_fwd", segs, n, G, metric, L.ptr(loss), L.ptr(stats), L.ptr(ws), ws.numel(), L.stream())
-    if any(need_grad):
-        L.call("dd3d_match_loss_bwd", segs, n, G, metric, L.ptr(stats), None, L.ptr(ws), ws.numel(), L.stream())
+    if any(need_grad):   # (one launch for small lists, the forward's two and the backward's one otherwise: the same bits)
+        L.call("dd3d_match_loss_fwd_bwd", segs, n, G, metric, L.ptr(loss), L.ptr(stats), None, L.ptr(ws), ws.numel(), L.stream())
+    else:
+        L.call("dd3d_match_loss_fwd", segs, n, G, metric, L.ptr(loss), L.ptr(stats), L.ptr(ws), ws.numel(), L.stream())
     return loss, dsyn
 
 

@@ -375,6 +375,12 @@ int dd3d_match_loss_fwd(const dd3d_gseg* segs, int n, int G, int metric, float* 
                         void* stream);
 int dd3d_match_loss_bwd(const dd3d_gseg* segs, int n, int G, int metric, const float* stats_dev, const float* gl_dev, void* ws, int64_t ws_bytes,
                         void* stream);
+/* dd3d_match_loss_fwd followed by dd3d_match_loss_bwd, same outputs bit for bit: ONE launch when the list is small (every segment row-major
+ * with at most 2048 columns, at most 8 rows in all -- e.g. an instance-norm weight's gradient, [1,128] per class), the three launches
+ * otherwise (longer lists are faster as wide launches: measured).  north_star (4): "a single segmented-reduction kernel" where a single kernel is the faster form.
+ * replaces: match_loss + the backward through it, mnist_distill.py:360,365 */
+int dd3d_match_loss_fwd_bwd(const dd3d_gseg* segs, int n, int G, int metric, float* loss_dev, float* stats_dev, const float* gl_dev, void* ws,
+                            int64_t ws_bytes, void* stream);
 
 /* x -= lr * (mom = first_step ? grad : momentum*mom + grad); optional clamp to [lo,hi] with column 0 of every xyz row forced to 0.
  * replaces: optimizer_img.step() and the next iteration's clamp, mnist_distill.py:369,311-317 */

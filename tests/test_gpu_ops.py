@@ -1,6 +1,8 @@
 """GPU parity tests, op by op: every C-ABI entry point of libdd3d_hip.so against the CPU oracle (oracle/minkowski_ref.py) on the
 same seeded inputs.  Integer outputs (coordinates, maps, pair lists) must be bit-exact; fp32 outputs are compared with an fp64
 oracle at rel 2e-5 of the tensor's max magnitude."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -455,6 +457,43 @@ def test_sparse_linear_bwd_w_layouts_groups_and_long_lists(B, J, gco):
         else:
             assert float(outs["param"][gi].abs().max()) == 0.0
     assert rel_err(outs["param"], ref) < 2e-5
+
+
+_SMALL_LOSS_SCRIPT = """
+import sys, torch
+sys.path.insert(0, %r)
+from dd3d_amd.fused_step import grouped_match_loss
+g = torch.Generator().manual_seed(11)
+G = 3
+shapes = [(1, 128), (4, 2000), (10,)]
+out = {}
+for metric in ("ours", "modmse", "mse", "cos"):
+    syn = [torch.randn((G,) + s, generator=g).cuda() for s in shapes]
+    real = [torch.randn((G,) + s, generator=g).cuda() for s in shapes]
+    loss, d = grouped_match_loss(syn, real, metric, G, [True, True, False])
+    loss2, _ = grouped_match_loss(syn[:1], real[:1], metric, G, [False])
+    out[metric] = [loss.cpu(), loss2.cpu(), d[0].cpu(), d[1].cpu()]
+torch.save(out, sys.argv[1])
+"""
+
+
+def test_one_launch_match_loss_is_bitwise_the_three_launches(tmp_path):
+    """dd3d_match_loss_fwd_bwd / dd3d_match_loss_fwd on a SMALL list (an instance-norm weight's gradient, [1,128] per class; here
+    six rows of at most 2000 columns, and the one-row list alone) run as one launch; the same seeded inputs in a process with DD3D_GD_SMALL=0 run as
+    the three launches.  Every loss and every gradient must have the same bits, for the four metrics."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("1", "0"):
+        f = str(tmp_path / f"loss_{flag}.pt")
+        env = dict(os.environ, DD3D_GD_SMALL=flag)
+        subprocess.run([sys.executable, "-c", _SMALL_LOSS_SCRIPT % root, f], check=True, env=env, timeout=240)
+        outs.append(torch.load(f))
+    for metric in ("ours", "modmse", "mse", "cos"):
+        for a, b in zip(outs[0][metric], outs[1][metric]):
+            assert torch.equal(a, b), metric
+        assert bool(torch.isfinite(outs[0][metric][0]).all())
 
 
 def test_loss_total_is_the_two_additions_and_the_sum():
