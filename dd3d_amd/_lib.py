@@ -103,7 +103,7 @@ _SIGS = {
     "dd3d_match_loss_bwd": (I32, [P, I32, I32, I32, P, P, P, I64, P]),
     "dd3d_match_loss_fwd_bwd": (I32, [P, I32, I32, I32, P, P, P, P, I64, P]),
     "dd3d_group_sum_rows": (I32, [P, P, I32, I32, P, P]),
-    "dd3d_loss_total": (I32, [P, P, P, I32, P, P, P]),
+    "dd3d_loss_total": (I32, [P, P, P, P, I32, P, P, P]),
     "dd3d_sgd_momentum_clamp": (I32, [P, P, P, I64, F32, F32, I32, I32, F32, F32, P]),
 }
 

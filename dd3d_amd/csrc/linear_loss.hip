@@ -394,16 +394,17 @@ __global__ __launch_bounds__(256) void k_cls_head(const float* __restrict__ part
     }
 }
 
-// per_class[g] = (a[g] + b[g]) + c[g] (b, c nullable) and total = sum_g per_class[g]: the three partial matching losses of a step and their
+// per_class[g] = ((a[g] + b[g]) + c[g]) + d[g] (b, c, d nullable) and total = sum_g per_class[g]: the partial matching losses of a step and their
 // sum in ONE launch (torch: two additions and a reduction, three dependent graph nodes at the very end of a step).  One wave; lane l adds
 // groups l, l + 64, ... in order, then the fixed shuffle tree of wave_sum: deterministic.
-__global__ void k_loss_total(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c, int G, float* __restrict__ per_class,
-                             float* __restrict__ total) {
+__global__ void k_loss_total(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c, const float* __restrict__ d, int G,
+                             float* __restrict__ per_class, float* __restrict__ total) {
     float s = 0.f;
     for (int g = threadIdx.x; g < G; g += 64) {
         float v = a[g];
         if (b) v += b[g];
         if (c) v += c[g];
+        if (d) v += d[g];
         if (per_class) per_class[g] = v;
         s += v;
     }
@@ -661,15 +662,17 @@ __global__ __launch_bounds__(256) void k_gd_bwd(const GPlan p, const float4* __r
     }
 }
 
-// k_gd_stats + k_gd_finalize (+ k_gd_bwd) in ONE launch for SMALL lists -- every segment row-contiguous with at most GD_SMALL_COLS columns and
-// at most GD_SMALL_ROWS rows in all: an instance-norm weight's gradient ([1,128] per class), the loss term that sits alone on the tail of a step.
-// Such a list is three dependent launches of a handful of workgroups each, i.e. ~20 us of dispatch latency for microseconds of work, twice on
-// the critical path of a step.  One workgroup per group walks the rows with EXACTLY the arithmetic of the three kernels (the same per-thread
-// element order, wave sums, four-wave combine, 256-slot pairwise tree, coefficients), so every output has the same bits.
-constexpr int GD_SMALL_ROWS = 8;      // a workgroup walks its rows one after the other: more rows (or longer ones) are faster as three wide launches
-constexpr int GD_SMALL_COLS = 2048;   // (measured: the twelve rows of up to 6272 columns of the classifier's gradients: +58 us per step in one launch)
+// k_gd_stats + k_gd_finalize (+ k_gd_bwd) in ONE launch for SMALL lists: at most GD_SMALL_PASSES block-wide passes in all -- a row-major row
+// of at most GD_SMALL_COLS columns is one pass, a column-major segment one pass per (128 rows, 64 columns) -- and at most 256 rows: an
+// instance-norm weight's gradient ([1,128] per class), the first layer's kernel gradient ([27,3,128]: 128 rows of 81), the terms that sit
+// alone on the tail of a step.  Such a list is three dependent launches of a handful of workgroups each, i.e. ~20 us of dispatch latency for
+// microseconds of work.  One workgroup per group walks the list with EXACTLY the arithmetic of the three kernels (the same per-thread element
+// order, wave sums, four-wave combine, half-block combine, chunk order, 256-slot pairwise tree, coefficients): every output has the same bits.
+constexpr int GD_SMALL_PASSES = 8;    // (a workgroup takes its passes one after the other: longer lists are faster as three wide launches --
+constexpr int GD_SMALL_COLS = 2048;   //  measured: the classifier's twelve rows of up to 6272 columns in one launch: +58 us per step)
 __global__ __launch_bounds__(256) void k_gd_small(const GPlan p, float4* __restrict__ stats, float* __restrict__ loss, const float* __restrict__ gl, int bwd) {
     __shared__ float s_red[4 * 4];
+    __shared__ float4 s_half[128];
     __shared__ float s_term[256];
     __shared__ float4 s_tot[256];
     const int tid = threadIdx.x, g = blockIdx.x;
@@ -678,46 +681,91 @@ __global__ __launch_bounds__(256) void k_gd_small(const GPlan p, float4* __restr
     s_term[tid] = 0.f;
     s_tot[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
-    for (int gr = 0; gr < total_rows; ++gr) {
-        int s = 0;
-        while (s + 1 < p.n && gr >= p.row_off[s + 1]) ++s;
+    for (int s = 0; s < p.n; ++s) {
         const dd3d_gseg sg = p.seg[s];
-        const int row = gr - p.row_off[s];
-        const int64_t goff = (int64_t)g * sg.rows * sg.cols, e1 = sg.cols;
-        const float* a = sg.syn + goff + row * sg.cols;
-        const float* b = sg.real + goff + row * sg.cols;
-        float dot = 0.f, ss = 0.f, rr = 0.f, sq = 0.f;
-        for (int64_t e = tid; e < e1; e += 256 * GD_U) {
-            float x[GD_U], y[GD_U];
+        const int64_t goff = (int64_t)g * sg.rows * sg.cols;
+        const float* syn = sg.syn + goff;
+        const float* real = sg.real + goff;
+        if (!sg.colmajor) {
+            for (int row = 0; row < sg.rows; ++row) {
+                const int gr = p.row_off[s] + row;
+                const int64_t e1 = sg.cols;
+                const float* a = syn + row * sg.cols;
+                const float* b = real + row * sg.cols;
+                float dot = 0.f, ss = 0.f, rr = 0.f, sq = 0.f;
+                for (int64_t e = tid; e < e1; e += 256 * GD_U) {
+                    float x[GD_U], y[GD_U];
 #pragma unroll
-            for (int j = 0; j < GD_U; ++j) {
-                const int64_t ej = e + 256 * j, ec = min(ej, e1 - 1);
-                x[j] = a[ec]; y[j] = b[ec];
-                if (ej >= e1) x[j] = y[j] = 0.f;
-            }
+                    for (int j = 0; j < GD_U; ++j) {
+                        const int64_t ej = e + 256 * j, ec = min(ej, e1 - 1);
+                        x[j] = a[ec]; y[j] = b[ec];
+                        if (ej >= e1) x[j] = y[j] = 0.f;
+                    }
 #pragma unroll
-            for (int j = 0; j < GD_U; ++j) {
-                const float d = x[j] - y[j];
-                dot += x[j] * y[j]; ss += x[j] * x[j]; rr += y[j] * y[j]; sq += d * d;
+                    for (int j = 0; j < GD_U; ++j) {
+                        const float d = x[j] - y[j];
+                        dot += x[j] * y[j]; ss += x[j] * x[j]; rr += y[j] * y[j]; sq += d * d;
+                    }
+                }
+                dot = wave_sum(dot); ss = wave_sum(ss); rr = wave_sum(rr); sq = wave_sum(sq);
+                if ((tid & 63) == 0) {
+                    const int w = tid >> 6;
+                    s_red[w * 4 + 0] = dot; s_red[w * 4 + 1] = ss; s_red[w * 4 + 2] = rr; s_red[w * 4 + 3] = sq;
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    float4 st = make_float4(0.f, 0.f, 0.f, 0.f);  // (k_gd_finalize adds the row's one chunk record into zeros)
+                    st.x += s_red[0] + s_red[4] + s_red[8] + s_red[12];
+                    st.y += s_red[1] + s_red[5] + s_red[9] + s_red[13];
+                    st.z += s_red[2] + s_red[6] + s_red[10] + s_red[14];
+                    st.w += s_red[3] + s_red[7] + s_red[11] + s_red[15];
+                    stats[gr] = st;
+                    s_term[gr] = row_term(p.metric, st);
+                    s_tot[gr] = st;
+                }
+                __syncthreads();
             }
+        } else {
+            const int nch = p.nchunk[s], half = tid >> 7;
+            for (int rt = 0; rt * 128 < sg.rows; ++rt) {
+                const int r = rt * 128 + (tid & 127);
+                float4 st = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int ch = 0; ch < nch; ++ch) {
+                    const int64_t q0 = (int64_t)ch * GD_COL_CHUNK, q1 = min(q0 + GD_COL_CHUNK, sg.cols);
+                    float dot = 0.f, ss = 0.f, rr = 0.f, sq = 0.f;
+                    if (r < sg.rows)
+                        for (int64_t q = q0 + half; q < q1; q += 2 * GD_U) {
+                            float x[GD_U], y[GD_U];
+#pragma unroll
+                            for (int j = 0; j < GD_U; ++j) {
+                                const int64_t qj = q + 2 * j, qc = min(qj, q1 - 1);
+                                x[j] = syn[qc * sg.rows + r]; y[j] = real[qc * sg.rows + r];
+                                if (qj >= q1) x[j] = y[j] = 0.f;
+                            }
+#pragma unroll
+                            for (int j = 0; j < GD_U; ++j) {
+                                const float d = x[j] - y[j];
+                                dot += x[j] * y[j]; ss += x[j] * x[j]; rr += y[j] * y[j]; sq += d * d;
+                            }
+                        }
+                    if (half == 1) s_half[tid & 127] = make_float4(dot, ss, rr, sq);
+                    __syncthreads();
+                    if (half == 0 && r < sg.rows) {
+                        const float4 t = s_half[tid];
+                        const float4 rec = make_float4(dot + t.x, ss + t.y, rr + t.z, sq + t.w);  // the (row, chunk) record of k_gd_stats ...
+                        st.x += rec.x; st.y += rec.y; st.z += rec.z; st.w += rec.w;               // ... added in chunk order, as k_gd_finalize does
+                    }
+                    __syncthreads();
+                }
+                if (half == 0 && r < sg.rows) {
+                    const int gr = p.row_off[s] + r;
+                    stats[gr] = st;
+                    s_term[gr] = row_term(p.metric, st);
+                    s_tot[gr] = st;
+                }
+            }
+            __syncthreads();
         }
-        dot = wave_sum(dot); ss = wave_sum(ss); rr = wave_sum(rr); sq = wave_sum(sq);
-        if ((tid & 63) == 0) {
-            const int w = tid >> 6;
-            s_red[w * 4 + 0] = dot; s_red[w * 4 + 1] = ss; s_red[w * 4 + 2] = rr; s_red[w * 4 + 3] = sq;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            float4 st = make_float4(0.f, 0.f, 0.f, 0.f);  // (k_gd_finalize adds the row's one chunk record into zeros)
-            st.x += s_red[0] + s_red[4] + s_red[8] + s_red[12];
-            st.y += s_red[1] + s_red[5] + s_red[9] + s_red[13];
-            st.z += s_red[2] + s_red[6] + s_red[10] + s_red[14];
-            st.w += s_red[3] + s_red[7] + s_red[11] + s_red[15];
-            stats[gr] = st;
-            s_term[gr] = row_term(p.metric, st);
-            s_tot[gr] = st;
-        }
-        __syncthreads();
     }
     for (int off = 128; off > 0; off >>= 1) {  // the pairwise tree of k_gd_finalize over the 256 slots (rows beyond total_rows hold zeros)
         if (tid < off) {
@@ -740,36 +788,65 @@ __global__ __launch_bounds__(256) void k_gd_small(const GPlan p, float4* __restr
         stats[total_rows] = tot;
     }
     if (!bwd) return;
-    __syncthreads();  // (workgroup-scope fence: the stats written by thread 0 are read back below)
+    __syncthreads();  // (workgroup-scope fence: the stats written above are read back below)
     const float up = gl ? gl[0] : 1.0f;
     const int metric = p.metric;
-    for (int gr = 0; gr < total_rows; ++gr) {
-        int s = 0;
-        while (s + 1 < p.n && gr >= p.row_off[s + 1]) ++s;
+    auto coef = [&](float4 st, float* ca, float* cb) {
+        const float nr = sqrtf(st.z), ns = sqrtf(st.y), den = nr * ns + 0.000001f;
+        *ca = -up / den;
+        *cb = ns > 0.f ? up * st.x * nr / (ns * den * den) : 0.f;
+    };
+    for (int s = 0; s < p.n; ++s) {
         const dd3d_gseg sg = p.seg[s];
         if (!sg.dsyn) continue;
-        const int row = gr - p.row_off[s];
-        const int64_t goff = (int64_t)g * sg.rows * sg.cols, e1 = sg.cols;
-        const float* a = sg.syn + goff + row * sg.cols;
-        const float* b = sg.real + goff + row * sg.cols;
-        float* d = sg.dsyn + goff + row * sg.cols;
-        float ca = 0.f, cb = 0.f;
-        if (metric == 0 || metric == 3) {
-            const float4 st = stats[metric == 0 ? gr : total_rows];
-            const float nr = sqrtf(st.z), ns = sqrtf(st.y), den = nr * ns + 0.000001f;
-            ca = -up / den;
-            cb = ns > 0.f ? up * st.x * nr / (ns * den * den) : 0.f;
-        }
-        for (int64_t e = tid; e < e1; e += 256 * GD_U) {
-            float x[GD_U], y[GD_U];
+        const int64_t goff = (int64_t)g * sg.rows * sg.cols;
+        const float* syn = sg.syn + goff;
+        const float* real = sg.real + goff;
+        float* dsyn = sg.dsyn + goff;
+        if (!sg.colmajor) {
+            for (int row = 0; row < sg.rows; ++row) {
+                const int64_t e1 = sg.cols;
+                const float* a = syn + row * sg.cols;
+                const float* b = real + row * sg.cols;
+                float* d = dsyn + row * sg.cols;
+                float ca = 0.f, cb = 0.f;
+                if (metric == 0) coef(stats[p.row_off[s] + row], &ca, &cb);
+                else if (metric == 3) coef(stats[total_rows], &ca, &cb);
+                for (int64_t e = tid; e < e1; e += 256 * GD_U) {
+                    float x[GD_U], y[GD_U];
 #pragma unroll
-            for (int j = 0; j < GD_U; ++j) {
-                const int64_t ec = min(e + 256 * j, e1 - 1);
-                x[j] = a[ec]; y[j] = b[ec];
+                    for (int j = 0; j < GD_U; ++j) {
+                        const int64_t ec = min(e + 256 * j, e1 - 1);
+                        x[j] = a[ec]; y[j] = b[ec];
+                    }
+#pragma unroll
+                    for (int j = 0; j < GD_U; ++j)
+                        if (e + 256 * j < e1) d[e + 256 * j] = (metric == 1 || metric == 2) ? 2.0f * up * (x[j] - y[j]) : ca * y[j] + cb * x[j];
+                }
             }
+        } else {
+            const int nch = p.nchunk[s], half = tid >> 7;
+            for (int rt = 0; rt * 128 < sg.rows; ++rt) {
+                const int r = rt * 128 + (tid & 127);
+                if (r >= sg.rows) continue;
+                float ca = 0.f, cb = 0.f;
+                if (metric == 0) coef(stats[p.row_off[s] + r], &ca, &cb);
+                else if (metric == 3) coef(stats[total_rows], &ca, &cb);
+                for (int ch = 0; ch < nch; ++ch) {
+                    const int64_t q0 = (int64_t)ch * GD_COL_CHUNK, q1 = min(q0 + GD_COL_CHUNK, sg.cols);
+                    for (int64_t q = q0 + half; q < q1; q += 2 * GD_U) {
+                        float x[GD_U], y[GD_U];
 #pragma unroll
-            for (int j = 0; j < GD_U; ++j)
-                if (e + 256 * j < e1) d[e + 256 * j] = (metric == 1 || metric == 2) ? 2.0f * up * (x[j] - y[j]) : ca * y[j] + cb * x[j];
+                        for (int j = 0; j < GD_U; ++j) {
+                            const int64_t ec = min(q + 2 * j, q1 - 1) * sg.rows + r;
+                            x[j] = syn[ec]; y[j] = real[ec];
+                        }
+#pragma unroll
+                        for (int j = 0; j < GD_U; ++j)
+                            if (q + 2 * j < q1) dsyn[(q + 2 * j) * sg.rows + r] = (metric == 1 || metric == 2) ? 2.0f * up * (x[j] - y[j]) : ca * y[j] + cb * x[j];
+                    }
+                }
+            }
         }
     }
 }
@@ -969,10 +1046,10 @@ DD3D_API int dd3d_group_sum_rows(const float* v, const int32_t* group_cloud_off,
     return 0;
 }
 
-// per_class[G] (nullable) = a + b + c elementwise (b, c nullable), *total (nullable) = their sum over the groups; one launch.
-DD3D_API int dd3d_loss_total(const float* a, const float* b, const float* c, int G, float* per_class, float* total, void* stream) {
+// per_class[G] (nullable) = a + b + c + d elementwise, left to right (b, c, d nullable), *total (nullable) = their sum over the groups; one launch.
+DD3D_API int dd3d_loss_total(const float* a, const float* b, const float* c, const float* d, int G, float* per_class, float* total, void* stream) {
     if (G < 0 || (G > 0 && !a)) return DD3D_EARG;
-    k_loss_total<<<1, 64, 0, (hipStream_t)stream>>>(a, b, c, G, per_class, total);
+    k_loss_total<<<1, 64, 0, (hipStream_t)stream>>>(a, b, c, d, G, per_class, total);
     DD3D_CHECK_LAUNCH();
     return 0;
 }
@@ -987,10 +1064,15 @@ DD3D_API int dd3d_softmax_ce_bwd2(const float* prob, const float* u, const float
 
 static bool plan_is_small(const GPlan& p) {
     static const bool off = getenv("DD3D_GD_SMALL") && !atoi(getenv("DD3D_GD_SMALL"));  // 0: always the three launches (measurements, tests)
-    if (off || p.row_off[p.n] > GD_SMALL_ROWS) return false;
-    for (int s = 0; s < p.n; ++s)
-        if (p.seg[s].colmajor || p.nchunk[s] != 1 || p.seg[s].cols > GD_SMALL_COLS) return false;
-    return true;
+    if (off || p.row_off[p.n] > 256) return false;
+    int64_t passes = 0;
+    for (int s = 0; s < p.n; ++s) {
+        const dd3d_gseg& g = p.seg[s];
+        if (g.colmajor) passes += ceil_div64(g.rows, 128) * p.nchunk[s];
+        else if (p.nchunk[s] != 1 || g.cols > GD_SMALL_COLS) return false;
+        else passes += g.rows;
+    }
+    return passes <= GD_SMALL_PASSES;
 }
 
 DD3D_API int64_t dd3d_match_loss_ws_bytes(const dd3d_gseg* segs, int n, int G) {

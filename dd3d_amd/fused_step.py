@@ -1172,9 +1172,15 @@ class FusedDistiller:
         elif so_early:
             loss_a1, hP0, ev_h = p.early_out
             loss_a2, d1 = grouped_match_loss([gw_syn[1]], [gw_real[1]], self.dist_opt, G, [True])   # the first level's IN weight
+            # The constant entries' loss terms, in two parts: the 128-channel kernel gradient and the second level's IN bias right behind
+            # that kernel gradient on its own stream (next to the first layer's kernel gradient, which ends last), the first layer's kernel
+            # gradient and IN bias behind it -- a list small enough for the one-launch form, so the tail of a step is kernel gradient ->
+            # slab sum -> ONE loss launch -> total instead of ... -> two loss launches over all four entries -> total
+            with torch.cuda.stream(side):
+                loss_b, _ = grouped_match_loss([gw_syn[i] for i in (3, 5)], [gw_real[i] for i in (3, 5)], self.dist_opt, G, [False] * 2)
             side.wait_stream(p.side2)
             with torch.cuda.stream(side):
-                loss_b, _ = grouped_match_loss([gw_syn[i] for i in const], [gw_real[i] for i in const], self.dist_opt, G, [False] * 4)
+                loss_b0, _ = grouped_match_loss([gw_syn[i] for i in (0, 2)], [gw_real[i] for i in (0, 2)], self.dist_opt, G, [False] * 2)
             main.wait_event(ev_h)
             dfeats = p.backward_from_conv(hP0, d1[0])
             # the update needs the point gradient only: it goes into the queue BEFORE the join with the loss terms of the constant entries
@@ -1184,8 +1190,9 @@ class FusedDistiller:
             main.wait_stream(side)
             if not static:
                 loss_b.record_stream(main)
+                loss_b0.record_stream(main)
             loss_g, total = torch.empty(G, dtype=_F32, device=dev), torch.empty((), dtype=_F32, device=dev)
-            L.call("dd3d_loss_total", L.ptr(loss_a1), L.ptr(loss_a2), L.ptr(loss_b), G, L.ptr(loss_g), L.ptr(total), L.stream())
+            L.call("dd3d_loss_total", L.ptr(loss_a1), L.ptr(loss_a2), L.ptr(loss_b), L.ptr(loss_b0), G, L.ptr(loss_g), L.ptr(total), L.stream())
         elif self.dist_opt in ("ours", "modmse", "mse") and os.environ.get("DD3D_LOSS_SPLIT", "1") != "0":
             main.wait_event(p.ev_cls)
             loss_a, d4 = grouped_match_loss([gw_syn[i] for i in diff], [gw_real[i] for i in diff], self.dist_opt, G, [True] * 4)

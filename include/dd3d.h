@@ -338,10 +338,10 @@ int dd3d_softmax_ce(const float* logits, const int32_t* labels, const int32_t* c
                     float* prob, float* dlogits, float* cloud_loss, float* loss_g, void* stream);
 int dd3d_group_sum_rows(const float* v, const int32_t* group_cloud_off, int G, int J, float* out, void* stream);
 
-/* per_class[G] = a + b + c (b, c nullable; the partial matching losses of a step, which are computed on different streams) and
- * *total = the sum over the groups, in one launch; per_class / total nullable.  Deterministic.
+/* per_class[G] = a + b + c + d, added left to right (b, c, d nullable; the partial matching losses of a step, which are computed on
+ * different streams) and *total = the sum over the groups, in one launch; per_class / total nullable.  Deterministic.
  * replaces: the running `loss +=` over the classes, mnist_distill.py:361 */
-int dd3d_loss_total(const float* a, const float* b, const float* c, int G, float* per_class, float* total, void* stream);
+int dd3d_loss_total(const float* a, const float* b, const float* c, const float* d, int G, float* per_class, float* total, void* stream);
 int dd3d_softmax_ce_bwd2(const float* prob, const float* u, const float* u_group /* [G,J] added to every cloud's u, nullable */,
                          const int32_t* group_cloud_off, int G, int J, int max_clouds_per_group, float* dz, void* stream);
 
@@ -375,9 +375,10 @@ int dd3d_match_loss_fwd(const dd3d_gseg* segs, int n, int G, int metric, float* 
                         void* stream);
 int dd3d_match_loss_bwd(const dd3d_gseg* segs, int n, int G, int metric, const float* stats_dev, const float* gl_dev, void* ws, int64_t ws_bytes,
                         void* stream);
-/* dd3d_match_loss_fwd followed by dd3d_match_loss_bwd, same outputs bit for bit: ONE launch when the list is small (every segment row-major
- * with at most 2048 columns, at most 8 rows in all -- e.g. an instance-norm weight's gradient, [1,128] per class), the three launches
- * otherwise (longer lists are faster as wide launches: measured).  north_star (4): "a single segmented-reduction kernel" where a single kernel is the faster form.
+/* dd3d_match_loss_fwd followed by dd3d_match_loss_bwd, same outputs bit for bit: ONE launch when the list is small (at most 8 block-wide
+ * passes in all: a row-major row of at most 2048 columns is one, a column-major segment one per 128 rows x 64 columns; at most 256 rows --
+ * e.g. an instance-norm weight's gradient, [1,128] per class, or the first layer's kernel gradient), the three launches otherwise (longer
+ * lists are faster as wide launches: measured).  dd3d_match_loss_fwd takes the same one-launch form for such lists.  north_star (4): "a single segmented-reduction kernel" where a single kernel is the faster form.
  * replaces: match_loss + the backward through it, mnist_distill.py:360,365 */
 int dd3d_match_loss_fwd_bwd(const dd3d_gseg* segs, int n, int G, int metric, float* loss_dev, float* stats_dev, const float* gl_dev, void* ws,
                             int64_t ws_bytes, void* stream);

@@ -465,21 +465,23 @@ sys.path.insert(0, %r)
 from dd3d_amd.fused_step import grouped_match_loss
 g = torch.Generator().manual_seed(11)
 G = 3
-shapes = [(1, 128), (4, 2000), (10,)]
+shapes = [(1, 128), (4, 2000), (10,), (27, 3, 128)]
 out = {}
 for metric in ("ours", "modmse", "mse", "cos"):
     syn = [torch.randn((G,) + s, generator=g).cuda() for s in shapes]
     real = [torch.randn((G,) + s, generator=g).cuda() for s in shapes]
-    loss, d = grouped_match_loss(syn, real, metric, G, [True, True, False])
+    loss, d = grouped_match_loss(syn, real, metric, G, [True, True, False, True])
     loss2, _ = grouped_match_loss(syn[:1], real[:1], metric, G, [False])
-    out[metric] = [loss.cpu(), loss2.cpu(), d[0].cpu(), d[1].cpu()]
+    loss3, _ = grouped_match_loss([syn[3], syn[0]], [real[3], real[0]], metric, G, [False, False])
+    out[metric] = [loss.cpu(), loss2.cpu(), loss3.cpu(), d[0].cpu(), d[1].cpu(), d[3].cpu()]
 torch.save(out, sys.argv[1])
 """
 
 
 def test_one_launch_match_loss_is_bitwise_the_three_launches(tmp_path):
-    """dd3d_match_loss_fwd_bwd / dd3d_match_loss_fwd on a SMALL list (an instance-norm weight's gradient, [1,128] per class; here
-    six rows of at most 2000 columns, and the one-row list alone) run as one launch; the same seeded inputs in a process with DD3D_GD_SMALL=0 run as
+    """dd3d_match_loss_fwd_bwd / dd3d_match_loss_fwd on a SMALL list (an instance-norm weight's gradient, [1,128] per class, the first
+    layer's kernel gradient [27,3,128], whose rows are its output channels; here six row-major rows of at most 2000 columns and that kernel
+    gradient, the one-row list alone, and the pair the step's tail uses) run as one launch; the same seeded inputs in a process with DD3D_GD_SMALL=0 run as
     the three launches.  Every loss and every gradient must have the same bits, for the four metrics."""
     import subprocess
     import sys
@@ -497,19 +499,20 @@ def test_one_launch_match_loss_is_bitwise_the_three_launches(tmp_path):
 
 
 def test_loss_total_is_the_two_additions_and_the_sum():
-    """dd3d_loss_total: per_class = (a + b) + c with torch's own bits, total = their sum (fp32 rounding of another order), nullable terms and
+    """dd3d_loss_total: per_class = ((a + b) + c) + d with torch's own bits, total = their sum (fp32 rounding of another order), nullable terms and
     outputs, more groups than lanes."""
     from dd3d_amd import _lib as L
     g = torch.Generator().manual_seed(2)
     for G in (1, 10, 40, 200):
         a, b, c = (torch.rand(G, generator=g).to(dev()) * 1e3 for _ in range(3))
         per, tot = torch.empty(G, device=dev()), torch.empty((), device=dev())
-        L.call("dd3d_loss_total", L.ptr(a), L.ptr(b), L.ptr(c), G, L.ptr(per), L.ptr(tot), L.stream())
-        assert torch.equal(per, (a + b) + c)
+        d = torch.rand(G, generator=g).to(dev()) * 1e3
+        L.call("dd3d_loss_total", L.ptr(a), L.ptr(b), L.ptr(c), L.ptr(d), G, L.ptr(per), L.ptr(tot), L.stream())
+        assert torch.equal(per, ((a + b) + c) + d)
         assert tot.item() == pytest.approx(per.double().sum().item(), rel=1e-6)
-        L.call("dd3d_loss_total", L.ptr(a), None, L.ptr(c), G, None, L.ptr(tot), L.stream())
+        L.call("dd3d_loss_total", L.ptr(a), None, L.ptr(c), None, G, None, L.ptr(tot), L.stream())
         assert tot.item() == pytest.approx((a + c).double().sum().item(), rel=1e-6)
-        L.call("dd3d_loss_total", L.ptr(a), None, None, G, L.ptr(per), None, L.stream())
+        L.call("dd3d_loss_total", L.ptr(a), None, None, None, G, L.ptr(per), None, L.stream())
         assert torch.equal(per, a)
 
 
