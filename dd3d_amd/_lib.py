@@ -143,6 +143,14 @@ def call(name: str, *args):
 
 
 _ws_cache = {}
+_ws_captured = {}      # key -> serial of the capture under which the block was last handed out (that graph keeps the address)
+_capture_serial = [0]
+
+
+def note_capture():
+    """Call right before opening a graph capture: workspaces handed out under an EARLIER capture are frozen from here on (a block may
+    still grow while the capture that first asked for it is being recorded -- stream-ordered reuse inside one recording is safe)."""
+    _capture_serial[0] += 1
 _ws_scope = ["ws"]
 
 
@@ -164,6 +172,7 @@ def drop_scope(tag: str):
     """Forget the workspaces of scope ``tag`` and of its sub-scopes (``tag`` + suffix)."""
     for k in [k for k in _ws_cache if k[2].startswith(tag)]:
         del _ws_cache[k]
+        _ws_captured.pop(k, None)
 
 
 _hip = None
@@ -189,9 +198,16 @@ def workspace(nbytes: int, device, tag: str = "ws") -> torch.Tensor:
         tag = _ws_scope[-1]
     key = (str(device), torch.cuda.current_stream(device).cuda_stream, tag)
     t = _ws_cache.get(key)
+    capturing = torch.cuda.is_current_stream_capturing()
     if t is None or t.numel() < nbytes:
+        if t is not None and key in _ws_captured and not (capturing and _ws_captured[key] == _capture_serial[0]):
+            # a FINISHED capture holds this block's ADDRESS: growing it would free memory that graph still writes on every replay
+            raise RuntimeError("workspace of a captured HIP graph cannot grow (%d -> %d bytes, scope %r): drop the graph and its scope first "
+                               "(FusedDistiller.invalidate / close)" % (t.numel(), nbytes, tag))
         t = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
         _ws_cache[key] = t
+    if capturing:   # (also a block the eager first step allocated: side streams keep their keys under capture)
+        _ws_captured[key] = _capture_serial[0]
     return t
 
 

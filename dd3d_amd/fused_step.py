@@ -680,8 +680,14 @@ class FusedDistiller:
         """Drop the captured graph and the cached weight layouts (transposed 128-channel kernel, site-major classifier weight).  Called
         automatically when a parameter's address or version counter changed since the capture; call it yourself after editing weights
         through ``.data`` (which bumps no version counter).  The next step runs eagerly and rebuilds the layouts, the one after re-captures."""
+        had_graph = self._graph is not None or any(g is not None for g in self._graphs)
         self._graph, self._graphs = None, [None, None]
         self._needs_eager = True
+        if had_graph:
+            # the dropped graphs' workspaces go with them, once nothing on the device can still be running a replay: a block that a captured
+            # graph was given is never regrown (_lib.workspace refuses), so the next capture must start from a clean scope
+            torch.cuda.synchronize(self.device)
+            L.drop_scope(self._scope)
         for p in self.network.parameters():
             for attr in ("_dd3d_csm", "_dd3d_wt", "_dd3d_sm"):
                 if hasattr(p, attr):
@@ -1019,6 +1025,7 @@ class FusedDistiller:
             loss = self._pipe_body(parity)
         elif pp.graphs[parity] is None:
             g = torch.cuda.CUDAGraph()
+            L.note_capture()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 loss = self._pipe_body(parity)
             pp.graphs[parity] = (g, loss, self.last)
@@ -1337,6 +1344,7 @@ class FusedDistiller:
             else:
                 if self._graphs[parity] is None:
                     g = torch.cuda.CUDAGraph()
+                    L.note_capture()
                     # thread_local: only this thread's calls are checked during capture (an RCCL watchdog thread polling its events
                     # must not invalidate it)
                     with torch.cuda.graph(g, capture_error_mode="thread_local"):

@@ -103,6 +103,35 @@ def test_fused_sampling_is_seeded_and_runs_at_bench_shape():
     assert np.isfinite(outs[0][0]).all()
 
 
+def test_workspace_of_a_finished_capture_cannot_grow():
+    """_lib.workspace: a block may grow while the capture that first asked for it is still being recorded (stream-ordered reuse inside one
+    recording), but once a capture has ended the graph holds the ADDRESS -- a larger request under the same (stream, scope) key, eager or
+    from a later capture, would free memory the graph writes on every replay, so it is refused until the scope is dropped."""
+    from dd3d_amd import _lib as L
+    side = torch.cuda.Stream(DEV)
+    tag = "guard-test"
+    g = torch.cuda.CUDAGraph()
+    L.note_capture()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        cur = torch.cuda.current_stream(DEV)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side), L.ws_scope(tag):
+            a = L.workspace(1024, DEV)
+            b = L.workspace(4096, DEV)        # the same recording: may grow
+            b.zero_()
+        cur.wait_stream(side)
+    assert a.numel() >= 1024 and b.numel() >= 4096
+    with torch.cuda.stream(side), L.ws_scope(tag):
+        assert L.workspace(4096, DEV).data_ptr() == b.data_ptr()      # fits: the same block
+        with pytest.raises(RuntimeError, match="cannot grow"):
+            L.workspace(1 << 20, DEV)
+    L.drop_scope(tag)
+    with torch.cuda.stream(side), L.ws_scope(tag):
+        assert L.workspace(1 << 20, DEV).numel() >= 1 << 20           # a clean scope again
+    L.drop_scope(tag)
+    del g
+
+
 def test_gather_clouds_equals_collate():
     """dd3d_gather_clouds (real batch assembled on the device from the point pool) against batch_from_images, which mirrors
     Mnist2Dreal.__getitem__ + minkowski_collate_fn (utils/Mnist2D.py:50-59, utils/MinkowskiCollate.py:4-15): same rows, same order,
