@@ -91,7 +91,7 @@ struct Maps {
     int B = 0, N = 0, S = 0;
     Level L0, L1, L2;
     std::vector<int> inv, cnt0, par1, par2, nbr0, nbr1, kid1, kid2, site;
-    bool ok = true;
+    bool ok = true, range_ok = true;
 };
 
 // k = (d0+1) + 3 (d1+1) + 9 (d2+1), d0 = first spatial column; table [27][M]
@@ -137,8 +137,16 @@ void build_maps(const double* coords, const int* off, int B, const dd3d_cpu_net&
     for (int b = 0; b < B; ++b)
         for (int i = off[b]; i < off[b + 1]; ++i) {
             q[(size_t)i * 4] = b;
-            for (int a = 0; a < 3; ++a) q[(size_t)i * 4 + 1 + a] = (int)std::floor(coords[(size_t)i * 3 + a]);
+            for (int a = 0; a < 3; ++a) {
+                const double f = std::floor(coords[(size_t)i * 3 + a]);
+                if (!(f > -32000.0 && f < 32000.0) || B > 65535) m.range_ok = false;  // the packed keys hold 16 bits per coordinate
+                q[(size_t)i * 4 + 1 + a] = (int)f;
+            }
         }
+    if (!m.range_ok) {
+        m.ok = false;
+        return;
+    }
     unique_rows(q, m.N, m.L0, m.inv, B);
     m.cnt0.assign(m.L0.M, 0);
     for (int i = 0; i < m.N; ++i) m.cnt0[m.inv[i]]++;
@@ -663,8 +671,8 @@ int class_step(const dd3d_cpu_net* cn, const double* rcoords, const T* rfeats, c
     Net<T> n{cn->J, cn->E0 * cn->E1 * cn->E2, (const T*)cn->W0, (const T*)cn->w1, (const T*)cn->b1, (const T*)cn->W1,
              (const T*)cn->w5, (const T*)cn->b5, (const T*)cn->Wc, (const T*)cn->bc};
     Pass<T> pr, ps;
-    if (!forward_backward(n, *cn, rcoords, rfeats, roff, Br, label, pr)) return -2;
-    if (!forward_backward(n, *cn, scoords, sfeats, soff, Bs, label, ps)) return -2;
+    if (!forward_backward(n, *cn, rcoords, rfeats, roff, Br, label, pr)) return pr.m.range_ok ? -2 : -3;
+    if (!forward_backward(n, *cn, scoords, sfeats, soff, Bs, label, ps)) return ps.m.range_ok ? -2 : -3;
     Vec<T> D[8];
     *loss = match_loss(ps.gw, pr.gw, metric, n.J, n.S, D);
     if (grad_sfeats) second_order(n, ps, D, grad_sfeats);
@@ -693,7 +701,8 @@ CPU_API void dd3d_cpu_prof_dump(void) {
 // One class of one matching step.  coords: [N,3] spatial coordinates ALREADY divided by the quantisation size (as doubles: a float value
 // is exact in a double, so the floor is the caller's); feats: [N,3]; off[B+1]: first point of every cloud.  Outputs: the class's
 // matching loss, d loss / d (synthetic features) [Ns,3] (nullable), the two gradient lists concatenated in parameters() order (nullable).
-// Returns 0, -1 for bad arguments, -2 when a stride-4 voxel falls outside the dense extent (MinkowskiEngine raises there).
+// Returns 0, -1 for bad arguments, -2 when a stride-4 voxel falls outside the dense extent (MinkowskiEngine raises there), -3 when a
+// coordinate does not fit the 16 bits per axis of this leg's packed voxel keys (|floor(c)| >= 32000, or more than 65535 clouds).
 CPU_API int dd3d_cpu_class_step_f64(const dd3d_cpu_net* n, const double* rc, const double* rf, const int* ro, int Br, const double* sc, const double* sf,
                                     const int* so, int Bs, int label, int metric, double* loss, double* grad, double* gw_real, double* gw_syn) {
     return class_step<double>(n, rc, rf, ro, Br, sc, sf, so, Bs, label, metric, loss, grad, gw_real, gw_syn);

@@ -104,6 +104,8 @@ def class_step(net: Network, real_clouds, syn_clouds, label, dist_opt="modmse", 
              p(loss), p(grad), p(gwr), p(gws))
     if rc_ == -2:
         raise RuntimeError("a stride-4 voxel lies outside the dense extent (MinkowskiEngine's dense() raises here)")
+    if rc_ == -3:
+        raise ValueError("a coordinate does not fit this leg's 16-bit voxel keys (|floor(c)| >= 32000, or more than 65535 clouds)")
     if rc_ != 0:
         raise ValueError("dd3d_cpu_class_step: bad arguments")
     return float(loss[0]), grad, (net.split(gwr) if want_lists else None), (net.split(gws) if want_lists else None)

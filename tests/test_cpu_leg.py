@@ -86,3 +86,7 @@ def test_cpu_leg_refuses_what_dense_refuses():
         CL.matching_step(net, far, [reals[0].numpy()], ipc, "modmse")
     with pytest.raises(ValueError):
         CL.class_step(net, CL.image_clouds(reals[0].numpy()), [syn.numpy()[0]], 10, "modmse")      # label outside the classifier's outputs
+    wide = syn.numpy().copy()
+    wide[0, 0] = [0.0, 4.0e4, 3.0]
+    with pytest.raises(ValueError, match="16-bit"):
+        CL.matching_step(net, wide, [reals[0].numpy()], ipc, "modmse")                              # beyond the packed voxel keys: refused, not aliased
