@@ -469,6 +469,7 @@ struct Pass {
     Vec<T> F0, Y0, xh0, is0, P0, Y1, xh1, is1, P1, logits, prob, dl, ga0, ga1;
     Vec<int> arg0, arg1;
     Vec<T> gw[8];  // order of network.parameters(): W0, w1, b1, W1, w5, b5, Wc, bc
+    Vec<T> gP1, gx1, gY1, gP0, gx0, gY0;  // scratch of the first-order backward (kept between calls: see class_step)
 };
 
 template <class T>
@@ -520,7 +521,9 @@ bool forward_backward(const Net<T>& n, const dd3d_cpu_net& cn, const double* coo
     linear_bwd_w(p.dl.data(), p.P1.data(), m, J, p.gw[6].data());
     for (int b = 0; b < B; ++b)
         for (int j = 0; j < J; ++j) p.gw[7][j] += p.dl[(size_t)b * J + j];
-    Vec<T> gP1((size_t)M2 * C), gx1((size_t)M1 * C), gY1((size_t)M1 * C), gP0((size_t)M1 * C), gx0((size_t)M0 * C), gY0((size_t)M0 * C);
+    Vec<T>&gP1 = p.gP1, &gx1 = p.gx1, &gY1 = p.gY1, &gP0 = p.gP0, &gx0 = p.gx0, &gY0 = p.gY0;  // (every element is written before it is read)
+    gP1.resize((size_t)M2 * C); gx1.resize((size_t)M1 * C); gY1.resize((size_t)M1 * C); gP0.resize((size_t)M1 * C);
+    gx0.resize((size_t)M0 * C); gY0.resize((size_t)M0 * C);
     linear_bwd_x(p.dl.data(), m, n.Wc, J, false, gP1.data());
     p.ga1.resize((size_t)M1 * C);
     affine_relu_pool_bwd(gP1.data(), p.arg1.data(), m.par2.data(), p.xh1.data(), n.w5, n.b5, M1, p.ga1.data(), gx1.data());
@@ -670,7 +673,11 @@ int class_step(const dd3d_cpu_net* cn, const double* rcoords, const T* rfeats, c
     if (!cn || Br <= 0 || Bs <= 0 || metric < 0 || metric > 3 || label < 0 || label >= cn->J) return -1;
     Net<T> n{cn->J, cn->E0 * cn->E1 * cn->E2, (const T*)cn->W0, (const T*)cn->w1, (const T*)cn->b1, (const T*)cn->W1,
              (const T*)cn->w5, (const T*)cn->b5, (const T*)cn->Wc, (const T*)cn->bc};
-    Pass<T> pr, ps;
+    // The two passes live on between calls (one set per arithmetic type): their ~60 MB of row buffers per class would otherwise be mapped,
+    // zeroed and unmapped again by every call -- a fifth of a step's time.  Single-threaded callers only (this is a test / baseline leg).
+    static Pass<T> pr, ps;
+    pr.m = Maps();
+    ps.m = Maps();
     if (!forward_backward(n, *cn, rcoords, rfeats, roff, Br, label, pr)) return pr.m.range_ok ? -2 : -3;
     if (!forward_backward(n, *cn, scoords, sfeats, soff, Bs, label, ps)) return ps.m.range_ok ? -2 : -3;
     Vec<T> D[8];
