@@ -90,3 +90,46 @@ def test_cpu_leg_refuses_what_dense_refuses():
     wide[0, 0] = [0.0, 4.0e4, 3.0]
     with pytest.raises(ValueError, match="16-bit"):
         CL.matching_step(net, wide, [reals[0].numpy()], ipc, "modmse")                              # beyond the packed voxel keys: refused, not aliased
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_cpu_leg_random_edge_cases_vs_torch_restatement(seed):
+    """Seeded random geometry, both legs in fp64: clouds of 1..40 points with negative coordinates, duplicate points, clouds that collapse
+    into ONE voxel (zero variance: x-hat = 0 * 1e4), one or several clouds per class, a random voxel size, a dense extent that just holds
+    them, 2..4 outputs, every metric."""
+    rng = np.random.default_rng(100 + seed)
+    nclass = int(rng.integers(2, 5))
+    ipc = int(rng.integers(1, 3))
+    vox = float(rng.choice([1.0, 0.5, 0.25]))
+    span = 10.0 * vox                                   # stride-4 voxels span 4 * vox: at most 4 sites per axis
+    ext = (4, 4, 4)
+    metric = ["modmse", "ours", "mse", "cos"][seed % 4]
+
+    def cloud():
+        n = int(rng.integers(1, 41))
+        kind = rng.integers(0, 4)
+        if kind == 0:                                   # everything in one voxel
+            pts = rng.uniform(0.1 * vox, 0.9 * vox, size=(n, 3)) + np.floor(rng.uniform(-span / 2, span / 2 - vox, size=3) / vox) * vox
+        else:
+            pts = rng.uniform(-span / 2, span / 2 - 1e-3, size=(n, 3))
+        if kind == 1 and n > 2:                         # exact duplicates
+            pts[n // 2:] = pts[:n - n // 2]
+        return np.round(pts, 4)
+
+    onet = R.MEConvExp(3, nclass, num_classes=nclass, dense_extent=ext)
+    onet.load_state_dict(det_state_dict(onet, "net.edge%d" % seed))
+    onet = onet.double().train()
+    reals = [[cloud() for _ in range(int(rng.integers(1, 5)))] for _ in range(nclass)]
+    npts = 24
+    syn = np.stack([np.round(rng.uniform(-span / 2, span / 2 - 1e-3, size=(npts, 3)), 4) for _ in range(nclass * ipc)])
+    ref = R.matching_step(onet, torch.tensor(syn).requires_grad_(), [[torch.tensor(c) for c in r] for r in reals], ipc, metric, False,
+                          num_points=1024, quantization_size=vox, coord_dtype=torch.float32)
+    got = CL.matching_step(CL.Network(onet, np.float64), syn, reals, ipc, metric, num_points=1024, quantization_size=vox, want_lists=True)
+    # (tolerance: a nearly constant channel of a tiny cloud has 1 / sqrt(var + 1e-8) up to 1e4, at both norm layers and again in their
+    # backward passes, which magnifies the two legs' different fp64 rounding to 1e-7 ... 1e-6 here; on ordinary clouds they agree to 1e-12)
+    assert np.isfinite(got["loss"]) and got["loss"] == pytest.approx(ref["loss"].item(), rel=1e-6)
+    g = ref["grad"].numpy()
+    assert np.abs(got["grad"] - g).max() <= 1e-5 * max(np.abs(g).max(), 1e-30)
+    for c in range(nclass):
+        for i in range(8):
+            assert rel(got["gw_syn"][c][i], ref["gw_syn"][c][i].numpy()) < 1e-5, (c, i)
