@@ -373,7 +373,7 @@ def cpu_baseline(images_all, indices_class, net, syn, args):
     x = syn.detach().cpu().double().numpy().copy()
     mom = np.zeros_like(x)
     imgs = images_all.cpu().numpy()
-    nsteps, t = 32, 0.0
+    nsteps, t = 64, 0.0
     for it in range(nsteps + 1):
         reals = [imgs[rng.permutation(indices_class[c])[:REAL_PER_CLASS]] for c in range(NUM_CLASSES)]
         t0 = time.perf_counter()
