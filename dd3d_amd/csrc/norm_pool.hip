@@ -626,6 +626,10 @@ __device__ __forceinline__ void arp_inorm_bwd_slice(const f32x4* __restrict__ g_
 // launch and an exact one sum in the same order.
 constexpr int ARP_WAVE_CACHE = 6;    // rows per lane kept in registers in wave mode (8 row-lanes: 48 rows; longer clouds re-read their tail from L2)
 constexpr int ARP_WAVE_ROWS = 128;   // clouds up to this many rows go wave by wave (measured at cfg2: 65.6 -> 30.8 us at level 2, 101 -> 88 us at level 1)
+constexpr int ARP_WAVE_ROWS_FEW = 64;      // ... in a launch over FEW clouds (the synthetic prefix of the second-order pass, a shard's batch) only
+constexpr int ARP_FEW_CLOUDS = 1024;       // up to this many rows: one workgroup per cloud leaves such a launch short of waves, four per cloud
+                                           // fill the chip (measured, round 3: second-order launches of 100 clouds 83 -> 61 and 48 -> 36 us,
+                                           // a 2-class shard's step 0.463 -> 0.436 ms; the merged launch of 2660 clouds is faster wave by wave)
 template <int RL, int CACHE, int CL>
 __global__ __launch_bounds__(RL * CL) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_arp_inorm_bwd(const f32x4* __restrict__ g_pool, const int4* __restrict__ arg, const int* __restrict__ parent,
                                                            const f32x4* __restrict__ xhat, const f32x4* __restrict__ inv_std,
@@ -839,7 +843,9 @@ static int arp_inorm_bwd_launch(const float* g_pool, const int32_t* arg, const i
         return DD3D_EARG;
     if (gw_w && (ws_bytes < dd3d_arp_inorm_bwd_ws_bytes(B) || !ws)) return DD3D_EWS;
     hipStream_t st = (hipStream_t)stream;
-    static const int wave_rows = getenv("DD3D_ARP_WAVE_ROWS") ? atoi(getenv("DD3D_ARP_WAVE_ROWS")) : ARP_WAVE_ROWS;  // 0: every cloud in workgroup mode (measurements)
+    // (a function of the cloud count alone, which a bound-sized launch and an exact one share: the same mode per cloud, the same sums)
+    static const int wave_env = getenv("DD3D_ARP_WAVE_ROWS") ? atoi(getenv("DD3D_ARP_WAVE_ROWS")) : -1;  // 0: every cloud in workgroup mode (measurements)
+    const int wave_rows = wave_env >= 0 ? wave_env : (B < ARP_FEW_CLOUDS ? ARP_WAVE_ROWS_FEW : ARP_WAVE_ROWS);
     if (B > 0) {
         if (!g_pool || !arg || !parent || !xhat || !inv_std || !seg_off || !dY) return DD3D_EARG;
         // 32 row-lanes x 8 float4 channel-lanes per workgroup, four workgroups per cloud (measured against 512- and 1024-thread shapes:
