@@ -1146,8 +1146,13 @@ DD3D_API int dd3d_conv_bwd_weight(const float* X, int Cin, const float* dY, int 
     static const int use_sk = getenv("DD3D_BWW_SK") ? atoi(getenv("DD3D_BWW_SK")) : 1;
     if (Cin == 128 && use_sk && G <= DD3D_BWW_MAX_GROUPS && M_out > 0) {
         // stream-K over the steps of all (group, offset) tiles: equal work per workgroup, accumulators resident across windows
-        static const int nwg_env = getenv("DD3D_BWW_NWG") ? atoi(getenv("DD3D_BWW_NWG")) : 512;
-        const int nwg = nwg_env < 8 ? 8 : nwg_env > DD3D_BWW_MAX_NWG ? DD3D_BWW_MAX_NWG : nwg_env / 8 * 8;
+        // persistent workgroups: two per CU; one per CU for the few groups of a shard (every workgroup leaves up to two partial slabs, and
+        // with little work per workgroup their sum is what a launch waits for: measured 0.545 -> 0.533 ms per step with 6 groups, 0.436 ->
+        // 0.429 with 4, 0.365 -> 0.359 with 2; from 10 groups on 512 is as fast or faster).  A function of the group count only, which the
+        // captured and the eager launch share.
+        static const int nwg_env = getenv("DD3D_BWW_NWG") ? atoi(getenv("DD3D_BWW_NWG")) : 0;
+        const int nwg_pick = nwg_env > 0 ? nwg_env : (G <= 8 ? 256 : 512);
+        const int nwg = nwg_pick < 8 ? 8 : nwg_pick > DD3D_BWW_MAX_NWG ? DD3D_BWW_MAX_NWG : nwg_pick / 8 * 8;
         return conv128_bww_sk(X, dY, nbr, ld, M_out, group_row_off, G, dW, ws, nwg, st);
     }
     if (M_out > 0) {

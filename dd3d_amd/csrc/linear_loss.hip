@@ -1062,9 +1062,12 @@ DD3D_API int dd3d_softmax_ce_bwd2(const float* prob, const float* u, const float
     return 0;
 }
 
-static bool plan_is_small(const GPlan& p) {
+constexpr int GD_SMALL_MIN_GROUPS = 8;  // one workgroup per group: with fewer groups the three launches spread the same work wider (measured on
+                                        // one-, two- and five-class shards: 0.357 / 0.431 / 0.699 ms per step against 0.365 / 0.436 / 0.705 in
+                                        // one launch; with ten groups the two forms take the same time)
+static bool plan_is_small(const GPlan& p, int G) {
     static const bool off = getenv("DD3D_GD_SMALL") && !atoi(getenv("DD3D_GD_SMALL"));  // 0: always the three launches (measurements, tests)
-    if (off || p.row_off[p.n] > 256) return false;
+    if (off || G < GD_SMALL_MIN_GROUPS || p.row_off[p.n] > 256) return false;
     int64_t passes = 0;
     for (int s = 0; s < p.n; ++s) {
         const dd3d_gseg& g = p.seg[s];
@@ -1097,7 +1100,7 @@ DD3D_API int dd3d_match_loss_fwd(const dd3d_gseg* segs, int n, int G, int metric
     if (!loss_dev || !stats_dev || G <= 0 || G > 65535) return DD3D_EARG;
     if (!ws || ws_bytes < dd3d_match_loss_ws_bytes(segs, n, G)) return DD3D_EWS;
     hipStream_t st = (hipStream_t)stream;
-    if (plan_is_small(p)) {  // one launch, the same bits
+    if (plan_is_small(p, G)) {  // one launch, the same bits
         k_gd_small<<<G, 256, 0, st>>>(p, (float4*)stats_dev, loss_dev, nullptr, 0);
         DD3D_CHECK_LAUNCH();
         return 0;
@@ -1117,7 +1120,7 @@ DD3D_API int dd3d_match_loss_fwd_bwd(const dd3d_gseg* segs, int n, int G, int me
     int rc = build_plan(segs, n, metric, &p);
     if (rc) return rc;
     if (!loss_dev || !stats_dev || G <= 0 || G > 65535) return DD3D_EARG;
-    if (plan_is_small(p)) {
+    if (plan_is_small(p, G)) {
         k_gd_small<<<G, 256, 0, (hipStream_t)stream>>>(p, (float4*)stats_dev, loss_dev, gl_dev, 1);
         DD3D_CHECK_LAUNCH();
         return 0;

@@ -377,8 +377,8 @@ int dd3d_match_loss_bwd(const dd3d_gseg* segs, int n, int G, int metric, const f
                         void* stream);
 /* dd3d_match_loss_fwd followed by dd3d_match_loss_bwd, same outputs bit for bit: ONE launch when the list is small (at most 8 block-wide
  * passes in all: a row-major row of at most 2048 columns is one, a column-major segment one per 128 rows x 64 columns; at most 256 rows --
- * e.g. an instance-norm weight's gradient, [1,128] per class, or the first layer's kernel gradient), the three launches otherwise (longer
- * lists are faster as wide launches: measured).  dd3d_match_loss_fwd takes the same one-launch form for such lists.  north_star (4): "a single segmented-reduction kernel" where a single kernel is the faster form.
+ * e.g. an instance-norm weight's gradient, [1,128] per class, or the first layer's kernel gradient) and there are at least 8 groups (one
+ * workgroup per group), the three launches otherwise (longer lists and fewer groups are faster as wide launches: measured).  dd3d_match_loss_fwd takes the same one-launch form for such lists.  north_star (4): "a single segmented-reduction kernel" where a single kernel is the faster form.
  * replaces: match_loss + the backward through it, mnist_distill.py:360,365 */
 int dd3d_match_loss_fwd_bwd(const dd3d_gseg* segs, int n, int G, int metric, float* loss_dev, float* stats_dev, const float* gl_dev, void* ws,
                             int64_t ws_bytes, void* stream);
