@@ -555,7 +555,8 @@ def test_deferred_loss_mode_is_the_same_step_one_step_later(metric):
 def test_cfg4_full_shape_step_properties():
     """BASELINE configs[3] at FULL shape -- 40 classes x 256 real clouds x 1024 points in [-1,1]^3, voxel 0.05, ipc 10, dense extent 12^3,
     10.9 M points and ~5 M voxel rows per step (k_cloud_emit<1024>, the second sort level of the launch schedule, the stream-K kernel
-    gradient with 80 groups) -- where the fp64 oracle would take hours.  Size-independent properties instead, over three steps:
+    gradient with 80 groups).  Size-independent properties over three steps (the values are checked against the fp64 oracle in
+    test_cfg4_full_size_graph_step_vs_oracle below):
     the HIP-graph replay equals the eager step bit for bit (loss, points, gradient); every map the LDS builder made for the LAST step's
     merged batch equals the global-hash builder's (coordinates at strides 1/2/4, cloud offsets, both kernel maps, both pooling maps,
     inverse map); error flags stay zero; the loss is finite and the update moves every owned cloud and nothing else."""
@@ -605,6 +606,127 @@ def test_cfg4_full_shape_step_properties():
         for m, (rm, _) in zip(maps, refmaps):
             Mo = ref.num_rows(m[1])
             assert torch.equal(cm.kernel_map(*m)[0][:, :Mo], rm[:, :Mo]), m
+
+
+def _classes_vs_cpp_leg(d, net64, clouds, order, pts, check, ipc, metric, q, tol=1e-4):
+    """Classes ``check`` (global class ids owned by distiller ``d``) of d's LAST step against the C++/OpenMP oracle leg in fp64
+    (oracle/cpu_leg.py, pinned by the torch restatement in tests/test_cpu_leg.py): ``pts`` = the clamped synthetic points the step started
+    from, ``order[c]`` = the step's sample of class c.  Every per-class loss within ``tol``; returns the classes whose xyz gradient is not
+    (a ReLU / arg-max flip between fp32 and fp64 in one synthetic cloud: the caller replays those on the device's branches)."""
+    from oracle import cpu_leg as CL
+    pc, grad = d.last["per_class"].cpu().double().numpy(), d.last["grad"].cpu().double().numpy()
+    off, worst_l, worst_g = [], 0.0, 0.0
+    for c in check:
+        gi = d.classes.index(c)
+        l, g, _, _ = CL.class_step(net64, [clouds[i].double().numpy() for i in order[c]], [pts[c * ipc + i] for i in range(ipc)], c, metric, q)
+        e_l = abs(pc[gi] - l) / abs(l)
+        mine = grad[c * ipc:(c + 1) * ipc].reshape(-1, 3)
+        e_g = float(np.linalg.norm(mine - g) / np.linalg.norm(g))
+        assert e_l < tol, (c, e_l)
+        worst_l = max(worst_l, e_l)
+        if e_g >= tol:
+            bad = int((np.abs(mine - g).max(1) > 1e-4 * np.abs(g).max()).sum())
+            print(f"   class {c}: xyz-grad rel {e_g:.2e} ({bad} of {g.shape[0]} points off)")
+            off.append(c)
+        else:
+            worst_g = max(worst_g, e_g)
+    print(f"   {len(check)} classes vs the C++ leg (fp64): worst per-class loss rel {worst_l:.2e}, worst xyz-grad rel {worst_g:.2e}, on a discontinuity: {off}")
+    return off
+
+
+def _replay_off_classes(d, onet, pts, clouds, order, off, ipc, metric, tol=1e-4, **step_kw):
+    """Classes ``off`` of d's last step against the fp64 torch oracle REPLAYED ON THE DEVICE'S ReLU / arg-max BRANCHES: loss, xyz gradient and
+    all eight entries of both gradient lists within ``tol`` -- what makes a class that failed the plain comparison a rounding-level branch flip
+    and not an error."""
+    osyn = torch.as_tensor(pts)
+    for c in off:
+        gi = d.classes.index(c)
+        reals = [None] * len(d.classes)
+        reals[gi] = [clouds[i].double() for i in order[c]]
+        fr = _oracle_on_device_branches(d, onet, osyn, reals, c, ipc, metric, **step_kw)
+        crow = torch.arange(c * ipc, (c + 1) * ipc)
+        e_l = rel_err(d.last["per_class"][gi:gi + 1], fr["per_class"])
+        e_g = rel_err(d.last["grad"][crow.to(DEV)], fr["grad"])
+        e_w = max(max(rel_err(d.last["gw_real"][i][gi].reshape(-1), fr["gw_real"][0][i].reshape(-1)),
+                      rel_err(d.last["gw_syn"][i][gi].reshape(-1), fr["gw_syn"][0][i].reshape(-1))) for i in range(8))
+        print(f"   class {c} replayed in fp64 on the device's branches: loss rel {e_l:.2e}, xyz-grad {e_g:.2e}, gw lists {e_w:.2e}")
+        assert e_l < tol and e_g < tol and e_w < tol, (c, e_l, e_g, e_w)
+
+
+def test_cfg4_full_size_graph_step_vs_oracle():
+    """BASELINE configs[3] at FULL size -- 40 classes x 256 real clouds x 1024 points, voxel 0.05, ipc 10, dense extent 12^3: the step
+    bench.py --config cfg4 times -- against the fp64 oracle, which at this size is its C++/OpenMP leg (about half a second per class on the
+    box's cores): step 0 (the bound-sized eager body) over every fourth class, step 1 (capture + replay) over ALL 40 classes; per-class
+    loss and xyz gradient within 1e-4.  With ~8e8 ReLU inputs per step a handful of them sit within fp32 rounding of zero and fp32 / fp64
+    take different branches there (measured: two classes per step, one or two points of one synthetic cloud each): those classes -- at
+    most four a step -- are replayed by the torch oracle on the device's branches and must meet the same 1e-4 there, gw lists included."""
+    from oracle import cpu_leg as CL
+    from dd3d_amd.fused_step import FusedDistiller
+    from dd3d_amd.models.MEConv import MEConvExp
+    from dd3d_amd.synthetic import shell_clouds
+    nclass, per, ipc, npts, q, ext = 40, 256, 10, 1024, 0.05, (12, 12, 12)
+    clouds = shell_clouds(nclass * per, npts, seed=0)
+    idx = [list(range(c * per, (c + 1) * per)) for c in range(nclass)]
+    syn = (torch.rand((nclass * ipc, npts, 3), generator=torch.Generator().manual_seed(0)) * 1.8 - 0.9).float()
+    torch.manual_seed(0)
+    m = MEConvExp(3, nclass, num_classes=nclass, dense_extent=ext)
+    m.load_state_dict(det_state_dict(m, "net.cfg4"))
+    net64 = CL.Network(m, np.float64)
+    onet = R.MEConvExp(3, nclass, num_classes=nclass, dense_extent=ext)
+    onet.load_state_dict(det_state_dict(onet, "net.cfg4"))
+    onet = onet.double().train()
+    rng = np.random.RandomState(5)
+    with FusedDistiller(None, idx, m.to(DEV).train(), graph=True, ipc=ipc, num_classes=nclass, num_points=npts, batch_size=per, device=DEV, seed=5,
+                        image_syn=syn, real_clouds=clouds, quantization_size=q, clamp_range=(-0.95, 0.95), zero_first_axis=False, dist_lr=1e-6) as f:
+        for step, check in enumerate([range(0, nclass, 4), range(nclass)]):
+            pts = f.image_syn.detach().cpu().clamp(-0.95, 0.95).double().numpy()
+            order = [rng.permutation(np.asarray(idx[c]))[:per] for c in range(nclass)]
+            loss = f.outer_step()
+            print(f"step {step} ({'eager body' if step == 0 else 'graph replay'}): loss {loss.item():.6g}")
+            off = _classes_vs_cpp_leg(f, net64, clouds, order, pts, check, ipc, "modmse", q)
+            assert len(off) <= 4, off
+            _replay_off_classes(f, onet, pts, clouds, order, off, ipc, "modmse", num_points=npts, quantization_size=q, coord_dtype=torch.float32)
+        f.check()
+        assert f._graph is not None and f.row_counts()[0][0] > 4_000_000
+
+
+def test_cfg5_full_size_chunked_step_vs_oracle():
+    """BASELINE configs[4] at FULL size -- 55 classes x 256 real clouds x 2048 points, voxel 0.02, ipc 10, dense extent 26^3 (a 2.25 M-column
+    classifier per class), five chunks of eleven classes in sequence as bench.py --config cfg5 runs it -- against the C++/OpenMP oracle leg
+    in fp64: every fifth class (one or two per chunk, ~3 s of host time each), per-class loss and xyz gradient within 1e-4; a class with a
+    ReLU / arg-max flip (measured: about one in five) replayed by the torch oracle on the device's branches, as in the cfg4 test."""
+    from oracle import cpu_leg as CL
+    from dd3d_amd.fused_step import ChunkedDistiller
+    from dd3d_amd.models.MEConv import MEConvExp
+    from dd3d_amd.synthetic import shell_clouds
+    nclass, per, ipc, npts, q, ext = 55, 256, 10, 2048, 0.02, (26, 26, 26)
+    clouds = shell_clouds(nclass * per, npts, seed=0)
+    idx = [list(range(c * per, (c + 1) * per)) for c in range(nclass)]
+    syn = (torch.rand((nclass * ipc, npts, 3), generator=torch.Generator().manual_seed(0)) * 1.8 - 0.9).float()
+    torch.manual_seed(0)
+    m = MEConvExp(3, nclass, num_classes=nclass, dense_extent=ext)
+    m.load_state_dict(det_state_dict(m, "net.cfg5"))
+    net64 = CL.Network(m, np.float64)
+    onet = R.MEConvExp(3, nclass, num_classes=nclass, dense_extent=ext)
+    onet.load_state_dict(det_state_dict(onet, "net.cfg5"))
+    onet = onet.double().train()
+    rng = np.random.RandomState(5)
+    cd = ChunkedDistiller(None, idx, m.to(DEV).train(), chunk=11, ipc=ipc, num_classes=nclass, num_points=npts, batch_size=per, device=DEV, seed=5,
+                          image_syn=syn, real_clouds=clouds, quantization_size=q, clamp_range=(-0.95, 0.95), zero_first_axis=False, dist_lr=1e-6)
+    try:
+        pts = cd.image_syn.detach().cpu().clamp(-0.95, 0.95).double().numpy()
+        order = [rng.permutation(np.asarray(idx[c]))[:per] for c in range(nclass)]   # the chunks draw from ONE stream, class after class
+        n_off = 0
+        for d in cd.parts:   # ChunkedDistiller.outer_step, with a look at every chunk before its lists go back to the allocator
+            d.outer_step()
+            d.check()
+            off = _classes_vs_cpp_leg(d, net64, clouds, order, pts, [c for c in d.classes if c % 5 == 0], ipc, "modmse", q)
+            _replay_off_classes(d, onet, pts, clouds, order, off, ipc, "modmse", num_points=npts, quantization_size=q, coord_dtype=torch.float32)
+            n_off += len(off)
+            d.last = {}
+        assert n_off <= 4, n_off
+    finally:
+        cd.close()
 
 
 @pytest.mark.parametrize("metric", ["modmse", "ours"])
