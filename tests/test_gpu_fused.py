@@ -618,7 +618,8 @@ def _classes_vs_cpp_leg(d, net64, clouds, order, pts, check, ipc, metric, q, tol
     off, worst_l, worst_g = [], 0.0, 0.0
     for c in check:
         gi = d.classes.index(c)
-        l, g, _, _ = CL.class_step(net64, [clouds[i].double().numpy() for i in order[c]], [pts[c * ipc + i] for i in range(ipc)], c, metric, q)
+        reals = CL.image_clouds(clouds[order[c]].numpy()) if torch.is_tensor(clouds) else [clouds[i].double().numpy() for i in order[c]]   # images or 3-D clouds
+        l, g, _, _ = CL.class_step(net64, reals, [pts[c * ipc + i] for i in range(ipc)], c, metric, q)
         e_l = abs(pc[gi] - l) / abs(l)
         mine = grad[c * ipc:(c + 1) * ipc].reshape(-1, 3)
         e_g = float(np.linalg.norm(mine - g) / np.linalg.norm(g))
@@ -642,7 +643,7 @@ def _replay_off_classes(d, onet, pts, clouds, order, off, ipc, metric, tol=1e-4,
     for c in off:
         gi = d.classes.index(c)
         reals = [None] * len(d.classes)
-        reals[gi] = [clouds[i].double() for i in order[c]]
+        reals[gi] = clouds[order[c]] if torch.is_tensor(clouds) else [clouds[i].double() for i in order[c]]
         fr = _oracle_on_device_branches(d, onet, osyn, reals, c, ipc, metric, **step_kw)
         crow = torch.arange(c * ipc, (c + 1) * ipc)
         e_l = rel_err(d.last["per_class"][gi:gi + 1], fr["per_class"])
@@ -651,6 +652,37 @@ def _replay_off_classes(d, onet, pts, clouds, order, off, ipc, metric, tol=1e-4,
                       rel_err(d.last["gw_syn"][i][gi].reshape(-1), fr["gw_syn"][0][i].reshape(-1))) for i in range(8))
         print(f"   class {c} replayed in fp64 on the device's branches: loss rel {e_l:.2e}, xyz-grad {e_g:.2e}, gw lists {e_w:.2e}")
         assert e_l < tol and e_g < tol and e_w < tol, (c, e_l, e_g, e_w)
+
+
+@pytest.mark.parametrize("metric,ipc,steps", [("ours", 10, 8), ("modmse", 50, 4), ("cos", 10, 3), ("mse", 10, 3)])
+def test_full_size_trajectory_vs_cpp_oracle(metric, ipc, steps):
+    """BASELINE configs[1] (ipc 10) and configs[2] (ipc 50) at FULL size -- 10 classes x 256 real clouds per step, the HIP-graph path -- over
+    a TRAJECTORY: before every step the C++/OpenMP oracle leg (fp64) takes the device's points and the step's sample and computes every
+    class's loss and xyz gradient; all four metrics of distillation_loss.match_loss.  Within 1e-4 at every step -- the eager body, the
+    capture and the replays over samples of different sizes -- except a class on a ReLU / arg-max flip (measured: at most one per step;
+    two are accepted), which is replayed on the device's branches like everywhere else.  ('ours', class 5: one such flip moves ALL of the
+    class's points by 2e-3 and the class's loss by 6e-5 in five of eight steps -- an output channel that is dead but for one borderline
+    element, so that the flip turns a whole row of the kernel gradient, and 'ours' takes the cosine per row; on the device's branches
+    the class agrees to 8e-7 like the others.)"""
+    from oracle import cpu_leg as CL
+    from dd3d_amd.fused_step import FusedDistiller
+    from dd3d_amd.synthetic import mnist3d_like
+    images, _, idx = mnist3d_like(10, 320, seed=2)
+    net = _net()
+    net64, onet = CL.Network(net, np.float64), _oracle_net()
+    rng = np.random.RandomState(13)
+    with FusedDistiller(images, idx, net, ipc=ipc, device=DEV, seed=13, image_syn=init_synthetic(10, ipc, 250, seed=4), dist_opt=metric, graph=True) as f:
+        for step in range(steps):
+            osyn = f.image_syn.detach().cpu().double().clone()
+            R.clamp_synthetic_(osyn)
+            order = [rng.permutation(np.asarray(idx[c]))[:256] for c in range(10)]
+            loss = f.outer_step()
+            print(f"step {step}: loss {loss.item():.6g}, rows {f.row_counts()[0]}")
+            off = _classes_vs_cpp_leg(f, net64, images, order, osyn.numpy(), range(10), ipc, metric, 1)
+            assert len(off) <= 2, off
+            _replay_off_classes(f, onet, osyn.numpy(), images, order, off, ipc, metric)
+        f.check()
+        assert f._graph is not None
 
 
 def test_cfg4_full_size_graph_step_vs_oracle():
