@@ -133,3 +133,25 @@ def test_cpu_leg_random_edge_cases_vs_torch_restatement(seed):
     for c in range(nclass):
         for i in range(8):
             assert rel(got["gw_syn"][c][i], ref["gw_syn"][c][i].numpy()) < 1e-5, (c, i)
+
+
+@pytest.mark.parametrize("metric", ["modmse", "ours"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_cpu_leg_vs_the_reference_golden_step(metric, dtype):
+    """The C++ leg DIRECTLY against tests/golden/g4_meconvexp.npz -- the matching step computed by the reference's own models/MEConv.py,
+    distillation_loss.py and mnist_distill.py loop body over the MinkowskiEngine restatement (tests/golden/make_golden.py; fp32) -- with the
+    inputs of tests/test_oracle_golden.py::test_meconvexp_step_oracle_vs_reference: loss, xyz gradient and the norm of every synthetic
+    gradient entry, at the tolerances that test holds the torch leg to."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g4_meconvexp.npz"))
+    torch.manual_seed(0)
+    onet = R.MEConvExp(in_channel=3, out_channel=10)
+    onet.load_state_dict(det_state_dict(onet, "net.MEConvExp"))
+    reals = [stroke_digits(4, seed=100 + c).numpy() for c in range(2)]
+    syn = init_synthetic(2, 2, num_points=250, seed=5)
+    R.clamp_synthetic_(syn)
+    out = CL.matching_step(CL.Network(onet, dtype), syn.numpy(), reals, 2, metric, want_lists=True)
+    assert out["loss"] == pytest.approx(float(g[metric + ".loss"]), rel=2e-5)
+    ref = g[metric + ".grad"]
+    assert np.abs(out["grad"] - ref).max() / np.abs(ref).max() < 1e-4
+    for c in range(2):
+        np.testing.assert_allclose([np.linalg.norm(t.astype(np.float64)) for t in out["gw_syn"][c]], g[metric + ".gws_norm"][c], rtol=1e-4)
