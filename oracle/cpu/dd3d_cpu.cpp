@@ -671,6 +671,7 @@ template <class T>
 int class_step(const dd3d_cpu_net* cn, const double* rcoords, const T* rfeats, const int* roff, int Br, const double* scoords, const T* sfeats,
                const int* soff, int Bs, int label, int metric, T* loss, T* grad_sfeats, T* gw_real, T* gw_syn) {
     if (!cn || Br <= 0 || Bs <= 0 || metric < 0 || metric > 3 || label < 0 || label >= cn->J) return -1;
+    if (!roff || !soff || roff[Br] <= roff[0] || soff[Bs] <= soff[0]) return -1;  // a batch without a single point (the reference's TensorField raises)
     Net<T> n{cn->J, cn->E0 * cn->E1 * cn->E2, (const T*)cn->W0, (const T*)cn->w1, (const T*)cn->b1, (const T*)cn->W1,
              (const T*)cn->w5, (const T*)cn->b5, (const T*)cn->Wc, (const T*)cn->bc};
     // The two passes live on between calls (one set per arithmetic type): their ~60 MB of row buffers per class would otherwise be mapped,

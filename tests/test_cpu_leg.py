@@ -90,6 +90,8 @@ def test_cpu_leg_refuses_what_dense_refuses():
     wide[0, 0] = [0.0, 4.0e4, 3.0]
     with pytest.raises(ValueError, match="16-bit"):
         CL.matching_step(net, wide, [reals[0].numpy()], ipc, "modmse")                              # beyond the packed voxel keys: refused, not aliased
+    with pytest.raises(ValueError):
+        CL.class_step(net, [np.zeros((0, 3))] * 4, [syn.numpy()[0]], 0, "modmse")                   # a real batch without a single point
 
 
 @pytest.mark.parametrize("seed", range(8))

@@ -618,12 +618,13 @@ def _classes_vs_cpp_leg(d, net64, clouds, order, pts, check, ipc, metric, q, tol
     off, worst_l, worst_g = [], 0.0, 0.0
     for c in check:
         gi = d.classes.index(c)
-        reals = CL.image_clouds(clouds[order[c]].numpy()) if torch.is_tensor(clouds) else [clouds[i].double().numpy() for i in order[c]]   # images or 3-D clouds
+        images = torch.is_tensor(clouds) and clouds.ndim == 4   # [n,1,28,28] digit images, or 3-D clouds [n][points,3]
+        reals = CL.image_clouds(clouds[order[c]].numpy()) if images else [clouds[i].double().numpy() for i in order[c]]
         l, g, _, _ = CL.class_step(net64, reals, [pts[c * ipc + i] for i in range(ipc)], c, metric, q)
         e_l = abs(pc[gi] - l) / abs(l)
         mine = grad[c * ipc:(c + 1) * ipc].reshape(-1, 3)
         e_g = float(np.linalg.norm(mine - g) / np.linalg.norm(g))
-        assert e_l < tol, (c, e_l)
+        assert e_l < tol, (c, e_l, float(pc[gi]), l, float(pc.sum()))
         worst_l = max(worst_l, e_l)
         if e_g >= tol:
             bad = int((np.abs(mine - g).max(1) > 1e-4 * np.abs(g).max()).sum())
@@ -643,7 +644,7 @@ def _replay_off_classes(d, onet, pts, clouds, order, off, ipc, metric, tol=1e-4,
     for c in off:
         gi = d.classes.index(c)
         reals = [None] * len(d.classes)
-        reals[gi] = clouds[order[c]] if torch.is_tensor(clouds) else [clouds[i].double() for i in order[c]]
+        reals[gi] = clouds[order[c]] if torch.is_tensor(clouds) and clouds.ndim == 4 else [clouds[i].double() for i in order[c]]
         fr = _oracle_on_device_branches(d, onet, osyn, reals, c, ipc, metric, **step_kw)
         crow = torch.arange(c * ipc, (c + 1) * ipc)
         e_l = rel_err(d.last["per_class"][gi:gi + 1], fr["per_class"])
