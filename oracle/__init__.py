@@ -16,5 +16,6 @@ no tests or fixtures at that boundary.
 
 Two legs that share no code and are tested against each other (``tests/test_cpu_leg.py``): the torch restatement
 (``minkowski_ref.py`` + ``ref_model.py``, what the golden fixtures pin) and a C++/OpenMP one (``cpu/dd3d_cpu.cpp`` behind
-``cpu_leg.py``; built by ``__graft_entry__.build()`` / ``make -C oracle/cpu``).
+``cpu_leg.py``; built by ``__graft_entry__.build()`` / ``make -C oracle/cpu``; interface in ``cpu/dd3d_cpu.h``: one class of a step, and the
+same restatement operator by operator on the array layouts of ``include/dd3d.h`` -- ``tests/test_cpu_leg_ops.py``).
 """

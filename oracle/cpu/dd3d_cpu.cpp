@@ -20,14 +20,9 @@
 #include <unordered_map>
 #include <vector>
 
-#define CPU_API extern "C" __attribute__((visibility("default")))
+#include "dd3d_cpu.h"  // the exported interface (dd3d_cpu_net: [27,3,128] [128] [128] [27,128,128] [128] [128] [J,128*S] [J], order of parameters())
 
-extern "C" {
-typedef struct dd3d_cpu_net {
-    int J, E0, E1, E2;  // outputs of the classifier, dense extent (models/MEConv.py:215,250: 10, (1,28,28))
-    const void *W0, *w1, *b1, *W1, *w5, *b5, *Wc, *bc;  // [27,3,128] [128] [128] [27,128,128] [128] [128] [J,128*S] [J], order of parameters()
-} dd3d_cpu_net;
-}
+#define CPU_API extern "C" __attribute__((visibility("default")))
 
 namespace {
 
@@ -565,10 +560,11 @@ template <class T>
 inline T& at(T* t, const RowView& v, int r, int q) { return t[r * v.row_stride + (q / v.n1) * v.e2 + (q % v.n1) * v.e1]; }
 
 // match_loss(gw_syn, gw_real, metric) and its gradient with respect to the entries of gw_syn listed in `need` (D[i] sized like gw[i])
+// (``need``: the entries of gw_syn that depend on the synthetic points in the reference's step -- the op-level entry point asks for all eight)
+constexpr bool kNeedStep[8] = {false, true, false, false, true, false, true, true};
 template <class T>
-T match_loss(const Vec<T>* gs, const Vec<T>* gr, int metric, int J, int S, Vec<T>* D) {
+T match_loss(const Vec<T>* gs, const Vec<T>* gr, int metric, int J, int S, Vec<T>* D, const bool* need = kNeedStep) {
     Tick tick_(7);
-    const bool need[8] = {false, true, false, false, true, false, true, true};
     T total = 0;
     if (metric == 0 || metric == 1) {  // "ours" (distance_wb per tensor) / "modmse" (distance_mse per tensor)
         for (int i = 0; i < 8; ++i) {
@@ -578,20 +574,23 @@ T match_loss(const Vec<T>* gs, const Vec<T>* gr, int metric, int J, int S, Vec<T
             T acc = 0;
 #pragma omp parallel for schedule(static) reduction(+ : acc) if (v.rows > 1)
             for (int row = 0; row < v.rows; ++row) {
+                // (sums over up to 128 * S elements are kept in double also in the fp32 variant: a running fp32 sum over 1e5 terms drifts by
+                // more than the 1e-4 this leg is held to, and torch's own fp32 reductions are pairwise)
                 if (metric == 1) {
-                    T t = 0;
+                    double t = 0;
                     for (int q = 0; q < v.cols; ++q) {
                         const T d = at(r, v, row, q) - at(s, v, row, q);
-                        t += d * d;
+                        t += (double)d * d;
                         if (need[i]) at(D[i].data(), v, row, q) = (T)-2 * d;
                     }
-                    acc += t;
+                    acc += (T)t;
                 } else {
-                    T rs = 0, rr = 0, ss = 0;
+                    double rs_ = 0, rr_ = 0, ss_ = 0;
                     for (int q = 0; q < v.cols; ++q) {
-                        const T a = at(r, v, row, q), b = at(s, v, row, q);
-                        rs += a * b; rr += a * a; ss += b * b;
+                        const double a = at(r, v, row, q), b = at(s, v, row, q);
+                        rs_ += a * b; rr_ += a * a; ss_ += b * b;
                     }
+                    const T rs = (T)rs_, rr = (T)rr_, ss = (T)ss_;
                     const T nr = std::sqrt(rr), ns = std::sqrt(ss), den = nr * ns + (T)1e-6;
                     acc += (T)1 - rs / den;
                     if (need[i])
@@ -604,12 +603,13 @@ T match_loss(const Vec<T>* gs, const Vec<T>* gr, int metric, int J, int S, Vec<T
             total += acc;
         }
     } else {  // "mse" / "cos" over the concatenation of all eight tensors
-        T rs = 0, rr = 0, ss = 0, sq = 0;
+        double rs_ = 0, rr_ = 0, ss_ = 0, sq_ = 0;
         for (int i = 0; i < 8; ++i)
             for (size_t e = 0; e < gs[i].size(); ++e) {
-                const T a = gr[i][e], b = gs[i][e];
-                rs += a * b; rr += a * a; ss += b * b; sq += (b - a) * (b - a);
+                const double a = gr[i][e], b = gs[i][e];
+                rs_ += a * b; rr_ += a * a; ss_ += b * b; sq_ += (b - a) * (b - a);
             }
+        const T rs = (T)rs_, rr = (T)rr_, ss = (T)ss_, sq = (T)sq_;
         const T nr = std::sqrt(rr), ns = std::sqrt(ss), den = nr * ns + (T)1e-6;
         total = metric == 2 ? sq : (T)1 - rs / den;
         for (int i = 0; i < 8; ++i) {
@@ -719,3 +719,257 @@ CPU_API int dd3d_cpu_class_step_f32(const dd3d_cpu_net* n, const double* rc, con
                                     const int* so, int Bs, int label, int metric, float* loss, float* grad, float* gw_real, float* gw_syn) {
     return class_step<float>(n, rc, rf, ro, Br, sc, sf, so, Bs, label, metric, loss, grad, gw_real, gw_syn);
 }
+
+
+// ================================================================================================================== op by op
+// The same restatement one operator at a time, on the array layouts of include/dd3d.h (int32 coordinate rows (batch, c1, c2, c3), neighbour
+// tables nbr[K][ld] with -1 = absent, children tables kids[8][ld], seg_off[B+1], arg-max rows, parent rows, flat site per pooled voxel), so
+// that a test can hand the arrays of a HIP call to the CPU leg and compare: maps bit for bit, features to rounding.  Host pointers, no
+// streams, no workspaces; every function returns 0, -1 (bad arguments), -2 (outside the dense extent) or -3 (beyond the 16-bit keys).
+// oracle/cpu/dd3d_cpu.h names the libdd3d_hip.so entry point each one mirrors.
+namespace {
+
+bool level_from_rows(const int32_t* rows, int64_t M, Level& lv) {
+    lv.M = (int)M;
+    lv.Cd.assign(rows, rows + 4 * M);
+    lv.tab.reserve((size_t)M * 2);
+    for (int64_t v = 0; v < M; ++v) {
+        const int32_t* c = rows + 4 * v;
+        if (c[0] < 0 || c[0] > 65535) return false;
+        for (int a = 1; a < 4; ++a)
+            if (c[a] <= -32000 || c[a] >= 32000) return false;
+        lv.tab.emplace(Key::pack(c[0], c[1], c[2], c[3]), (int)v);
+    }
+    return true;
+}
+
+// a [K][ld] table as the [K][M] table the loops above index
+const int* dense_table(const int32_t* t, int64_t ld, int64_t M, int K, std::vector<int>& tmp) {
+    if (ld == M) return t;
+    tmp.resize((size_t)K * M);
+    for (int k = 0; k < K; ++k) std::memcpy(&tmp[(size_t)k * M], t + (size_t)k * ld, sizeof(int) * M);
+    return tmp.data();
+}
+
+void maps_for_linear(const int32_t* site, int64_t M2, const int32_t* seg_off, int B, int S, Maps& m) {
+    m.B = B;
+    m.S = S;
+    m.L2.M = (int)M2;
+    m.L2.seg.assign(seg_off, seg_off + B + 1);
+    m.L2.Cd.assign((size_t)M2 * 4, 0);
+    for (int b = 0; b < B; ++b)
+        for (int v = seg_off[b]; v < seg_off[b + 1]; ++v) m.L2.Cd[(size_t)v * 4] = b;
+    m.site.assign(site, site + M2);
+}
+
+template <class T>
+int op_match_loss(const T* gw_syn, const T* gw_real, int J, int S, int metric, T* loss, T* d_gw_syn) {
+    if (!gw_syn || !gw_real || !loss || J <= 0 || S <= 0 || metric < 0 || metric > 3) return -1;
+    int64_t off[8];
+    const int64_t total = param_offsets<T>(J, S, off);
+    Vec<T> gs[8], gr[8], D[8];
+    for (int i = 0; i < 8; ++i) {
+        const int64_t n = (i < 7 ? off[i + 1] : total) - off[i];
+        gs[i].assign(gw_syn + off[i], gw_syn + off[i] + n);
+        gr[i].assign(gw_real + off[i], gw_real + off[i] + n);
+    }
+    const bool all[8] = {true, true, true, true, true, true, true, true};
+    *loss = match_loss(gs, gr, metric, J, S, D, all);
+    if (d_gw_syn)
+        for (int i = 0; i < 8; ++i) std::memcpy(d_gw_syn + off[i], D[i].data(), sizeof(T) * D[i].size());
+    return 0;
+}
+
+template <class T>
+int op_softmax_ce(const T* logits, const int32_t* labels, int B, int J, T* loss, T* dlogits) {
+    if (!logits || !labels || B <= 0 || J <= 0) return -1;
+    T total = 0;
+    for (int b = 0; b < B; ++b) {
+        const T* z = logits + (size_t)b * J;
+        if (labels[b] < 0 || labels[b] >= J) return -1;
+        T mx = z[0];
+        for (int j = 1; j < J; ++j) mx = std::max(mx, z[j]);
+        T se = 0;
+        for (int j = 0; j < J; ++j) se += std::exp(z[j] - mx);
+        const T lse = mx + std::log(se);
+        total += lse - z[labels[b]];
+        if (dlogits)
+            for (int j = 0; j < J; ++j) dlogits[(size_t)b * J + j] = (std::exp(z[j] - lse) - (j == labels[b] ? (T)1 : (T)0)) / (T)B;
+    }
+    if (loss) *loss = total / (T)B;
+    return 0;
+}
+
+}  // namespace
+
+CPU_API int dd3d_cpu_quantize_unique(const double* coords, const int32_t* pt_off, int B, int32_t* Cq, int32_t* inv, int32_t* seg_off, int64_t* M) {
+    if (!coords || !pt_off || B <= 0 || B > 65535 || !Cq || !inv || !seg_off || !M) return -1;
+    const int N = pt_off[B];
+    std::vector<int> q((size_t)N * 4), map;
+    for (int b = 0; b < B; ++b)
+        for (int i = pt_off[b]; i < pt_off[b + 1]; ++i) {
+            q[(size_t)i * 4] = b;
+            for (int a = 0; a < 3; ++a) {
+                const double f = std::floor(coords[(size_t)i * 3 + a]);
+                if (!(f > -32000.0 && f < 32000.0)) return -3;
+                q[(size_t)i * 4 + 1 + a] = (int)f;
+            }
+        }
+    Level lv;
+    unique_rows(q, N, lv, map, B);
+    std::memcpy(Cq, lv.Cd.data(), sizeof(int) * lv.Cd.size());
+    std::memcpy(inv, map.data(), sizeof(int) * (size_t)N);
+    std::memcpy(seg_off, lv.seg.data(), sizeof(int) * (size_t)(B + 1));
+    *M = lv.M;
+    return 0;
+}
+
+CPU_API int dd3d_cpu_stride_coords(const int32_t* Cin, int64_t M_in, int B, int stride, int32_t* Cout, int32_t* parent, int32_t* seg_off, int64_t* M_out) {
+    if (!Cin || M_in < 0 || B <= 0 || stride <= 0 || !Cout || !parent || !seg_off || !M_out) return -1;
+    Level in, out;
+    in.M = (int)M_in;
+    in.Cd.assign(Cin, Cin + 4 * M_in);
+    std::vector<int> par;
+    stride_up(in, stride, out, par, B);
+    std::memcpy(Cout, out.Cd.data(), sizeof(int) * out.Cd.size());
+    std::memcpy(parent, par.data(), sizeof(int) * (size_t)M_in);
+    std::memcpy(seg_off, out.seg.data(), sizeof(int) * (size_t)(B + 1));
+    *M_out = out.M;
+    return 0;
+}
+
+CPU_API int dd3d_cpu_kernel_map(const int32_t* Cq, int64_t M, int tensor_stride, int32_t* nbr) {
+    if (!Cq || M < 0 || tensor_stride <= 0 || !nbr) return -1;
+    Level lv;
+    if (!level_from_rows(Cq, M, lv)) return -3;
+    std::vector<int> t;
+    kernel_map3(lv, tensor_stride, t);
+    std::memcpy(nbr, t.data(), sizeof(int) * t.size());
+    return 0;
+}
+
+CPU_API int dd3d_cpu_pool_map(const int32_t* Cin, int64_t M_in, const int32_t* Cout, int64_t M_out, int tensor_stride_in, int32_t* kids) {
+    if (!Cin || !Cout || M_in < 0 || M_out < 0 || tensor_stride_in <= 0 || !kids) return -1;
+    Level in, out;
+    if (!level_from_rows(Cin, M_in, in)) return -3;
+    out.M = (int)M_out;
+    out.Cd.assign(Cout, Cout + 4 * M_out);
+    std::vector<int> t;
+    pool_map(in, out, tensor_stride_in, t);
+    std::memcpy(kids, t.data(), sizeof(int) * t.size());
+    return 0;
+}
+
+CPU_API int dd3d_cpu_dense_sites(const int32_t* Cq, int64_t M, int tensor_stride, int E0, int E1, int E2, int32_t* site) {
+    if (!Cq || M <= 0 || tensor_stride <= 0 || E0 <= 0 || E1 <= 0 || E2 <= 0 || !site) return -1;
+    int mn[3] = {INT32_MAX, INT32_MAX, INT32_MAX};
+    for (int64_t v = 0; v < M; ++v)
+        for (int a = 0; a < 3; ++a) mn[a] = std::min(mn[a], Cq[v * 4 + 1 + a]);
+    for (int64_t v = 0; v < M; ++v) {
+        const int32_t* c = Cq + v * 4;
+        const int a = (c[1] - mn[0]) / tensor_stride, d = (c[2] - mn[1]) / tensor_stride, e = (c[3] - mn[2]) / tensor_stride;
+        if (a >= E0 || d >= E1 || e >= E2) return -2;
+        site[v] = (a * E1 + d) * E2 + e;
+    }
+    return 0;
+}
+
+#define DD3D_CPU_OPS(T, SFX)                                                                                                                          \
+    CPU_API int dd3d_cpu_voxel_mean_fwd_##SFX(const T* feats, int64_t N, int Cf, const int32_t* inv, int64_t M, T* F0) {                             \
+        if (!feats || !inv || !F0 || N < 0 || M < 0 || Cf <= 0) return -1;                                                                           \
+        std::vector<int> cnt((size_t)M, 0);                                                                                                          \
+        std::fill(F0, F0 + (size_t)M * Cf, (T)0);                                                                                                    \
+        for (int64_t i = 0; i < N; ++i) {                                                                                                            \
+            if (inv[i] < 0 || inv[i] >= M) return -1;                                                                                                \
+            cnt[inv[i]]++;                                                                                                                           \
+            for (int a = 0; a < Cf; ++a) F0[(size_t)inv[i] * Cf + a] += feats[(size_t)i * Cf + a];                                                   \
+        }                                                                                                                                            \
+        for (int64_t v = 0; v < M; ++v)                                                                                                              \
+            for (int a = 0; a < Cf; ++a) F0[(size_t)v * Cf + a] /= (T)std::max(cnt[v], 1);                                                           \
+        return 0;                                                                                                                                    \
+    }                                                                                                                                                \
+    CPU_API int dd3d_cpu_voxel_mean_bwd_##SFX(const T* dF0, int64_t M, int Cf, const int32_t* inv, int64_t N, T* dfeats) {                           \
+        if (!dF0 || !inv || !dfeats || N < 0 || M < 0 || Cf <= 0) return -1;                                                                         \
+        std::vector<int> cnt((size_t)M, 0);                                                                                                          \
+        for (int64_t i = 0; i < N; ++i) {                                                                                                            \
+            if (inv[i] < 0 || inv[i] >= M) return -1;                                                                                                \
+            cnt[inv[i]]++;                                                                                                                           \
+        }                                                                                                                                            \
+        for (int64_t i = 0; i < N; ++i)                                                                                                              \
+            for (int a = 0; a < Cf; ++a) dfeats[(size_t)i * Cf + a] = dF0[(size_t)inv[i] * Cf + a] / (T)cnt[inv[i]];                                 \
+        return 0;                                                                                                                                    \
+    }                                                                                                                                                \
+    CPU_API int dd3d_cpu_conv_fwd_##SFX(const T* X, int Cin, const T* W, int Cout, const int32_t* nbr, int64_t ld, int64_t M, T* Y) {                \
+        if (!X || !W || !nbr || !Y || Cin <= 0 || Cout <= 0 || M < 0 || ld < M) return -1;                                                           \
+        std::vector<int> tmp;                                                                                                                        \
+        conv_fwd(X, Cin, W, Cout, dense_table(nbr, ld, M, 27, tmp), (int)M, Y);                                                                      \
+        return 0;                                                                                                                                    \
+    }                                                                                                                                                \
+    CPU_API int dd3d_cpu_conv_bwd_data_##SFX(const T* dY, int Cout, const T* W, int Cin, const int32_t* nbr, int64_t ld, int64_t M, T* dX) {         \
+        if (!dY || !W || !nbr || !dX || Cin <= 0 || Cout <= 0 || M < 0 || ld < M) return -1;                                                         \
+        std::vector<int> tmp;                                                                                                                        \
+        conv_bwd_data(dY, Cout, W, Cin, dense_table(nbr, ld, M, 27, tmp), (int)M, dX);                                                               \
+        return 0;                                                                                                                                    \
+    }                                                                                                                                                \
+    CPU_API int dd3d_cpu_conv_bwd_weight_##SFX(const T* X, int Cin, const T* dY, int Cout, const int32_t* nbr, int64_t ld, int64_t M, T* dW) {       \
+        if (!X || !dY || !nbr || !dW || Cin <= 0 || Cout <= 0 || M < 0 || ld < M) return -1;                                                         \
+        std::vector<int> tmp;                                                                                                                        \
+        conv_bwd_weight(X, Cin, dY, Cout, dense_table(nbr, ld, M, 27, tmp), (int)M, dW);                                                             \
+        return 0;                                                                                                                                    \
+    }                                                                                                                                                \
+    CPU_API int dd3d_cpu_inorm_fwd_##SFX(const T* Y, const int32_t* seg_off, int B, int Cc, T* xhat, T* inv_std) {                                   \
+        if (!Y || !seg_off || !xhat || !inv_std || B <= 0 || Cc != C) return -1;                                                                     \
+        inorm_fwd(Y, std::vector<int>(seg_off, seg_off + B + 1), B, xhat, inv_std);                                                                  \
+        return 0;                                                                                                                                    \
+    }                                                                                                                                                \
+    CPU_API int dd3d_cpu_inorm_bwd_##SFX(const T* g, const T* xhat, const T* inv_std, const int32_t* seg_off, int B, int Cc, T* dY) {                \
+        if (!g || !xhat || !inv_std || !seg_off || !dY || B <= 0 || Cc != C) return -1;                                                              \
+        inorm_bwd(g, xhat, inv_std, std::vector<int>(seg_off, seg_off + B + 1), B, dY);                                                              \
+        return 0;                                                                                                                                    \
+    }                                                                                                                                                \
+    CPU_API int dd3d_cpu_affine_relu_pool_fwd_##SFX(const T* xhat, const T* w, const T* b, int Cc, const int32_t* kids, int64_t ld, int64_t M_out,   \
+                                                    T* out, int32_t* arg) {                                                                          \
+        if (!xhat || !w || !b || !kids || !out || !arg || Cc != C || M_out < 0 || ld < M_out) return -1;                                             \
+        std::vector<int> tmp;                                                                                                                        \
+        affine_relu_pool_fwd(xhat, w, b, dense_table(kids, ld, M_out, 8, tmp), (int)M_out, out, arg);                                                \
+        return 0;                                                                                                                                    \
+    }                                                                                                                                                \
+    CPU_API int dd3d_cpu_affine_relu_pool_bwd_##SFX(const T* g_pool, const int32_t* arg, const int32_t* parent, const T* xhat, const T* w,           \
+                                                    const T* b, int Cc, int64_t M_in, T* ga, T* g_xhat) {                                            \
+        if (!g_pool || !arg || !parent || !xhat || !w || !b || !ga || !g_xhat || Cc != C || M_in < 0) return -1;                                     \
+        affine_relu_pool_bwd(g_pool, arg, parent, xhat, w, b, (int)M_in, ga, g_xhat);                                                                \
+        return 0;                                                                                                                                    \
+    }                                                                                                                                                \
+    CPU_API int dd3d_cpu_sparse_linear_fwd_##SFX(const T* F, const int32_t* site, int64_t M, const int32_t* seg_off, int B, int Cc, int S,           \
+                                                 const T* Wc, const T* bias, int J, T* logits) {                                                     \
+        if (!F || !site || !seg_off || !Wc || !logits || Cc != C || B <= 0 || S <= 0 || J <= 0 || M < 0) return -1;                                  \
+        Maps m;                                                                                                                                      \
+        maps_for_linear(site, M, seg_off, B, S, m);                                                                                                  \
+        linear_fwd(F, m, Wc, bias, J, logits);                                                                                                       \
+        return 0;                                                                                                                                    \
+    }                                                                                                                                                \
+    CPU_API int dd3d_cpu_sparse_linear_bwd_x_##SFX(const T* dl, const int32_t* site, int64_t M, const int32_t* seg_off, int B, int Cc, int S,        \
+                                                   const T* Wc, int J, T* dF) {                                                                      \
+        if (!dl || !site || !seg_off || !Wc || !dF || Cc != C || B <= 0 || S <= 0 || J <= 0 || M < 0) return -1;                                     \
+        Maps m;                                                                                                                                      \
+        maps_for_linear(site, M, seg_off, B, S, m);                                                                                                  \
+        linear_bwd_x(dl, m, Wc, J, false, dF);                                                                                                       \
+        return 0;                                                                                                                                    \
+    }                                                                                                                                                \
+    CPU_API int dd3d_cpu_sparse_linear_bwd_w_##SFX(const T* dl, const T* F, const int32_t* site, int64_t M, const int32_t* seg_off, int B, int Cc,   \
+                                                   int S, int J, T* gW) {                                                                            \
+        if (!dl || !F || !site || !seg_off || !gW || Cc != C || B <= 0 || S <= 0 || J <= 0 || M < 0) return -1;                                      \
+        Maps m;                                                                                                                                      \
+        maps_for_linear(site, M, seg_off, B, S, m);                                                                                                  \
+        linear_bwd_w(dl, F, m, J, gW);                                                                                                               \
+        return 0;                                                                                                                                    \
+    }                                                                                                                                                \
+    CPU_API int dd3d_cpu_softmax_ce_##SFX(const T* logits, const int32_t* labels, int B, int J, T* loss, T* dlogits) {                               \
+        return op_softmax_ce<T>(logits, labels, B, J, loss, dlogits);                                                                                \
+    }                                                                                                                                                \
+    CPU_API int dd3d_cpu_match_loss_##SFX(const T* gw_syn, const T* gw_real, int J, int S, int metric, T* loss, T* d_gw_syn) {                       \
+        return op_match_loss<T>(gw_syn, gw_real, J, S, metric, loss, d_gw_syn);                                                                      \
+    }
+
+DD3D_CPU_OPS(double, f64)
+DD3D_CPU_OPS(float, f32)

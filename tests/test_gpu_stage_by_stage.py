@@ -1,0 +1,89 @@
+"""One full-size cfg2 step on the GPU, taken apart stage by stage against the op-level entry points of the oracle's C++/OpenMP leg
+(oracle/cpu/dd3d_cpu.h): the merged batch's coordinate maps bit for bit, then every forward stage from the DEVICE's own input of that stage
+(so an error cannot hide behind, or be blamed on, the stage before it), then the first-order parameter gradients of one class."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_leg as CL
+from dd3d_amd.synthetic import init_synthetic, mnist3d_like
+from tests.detgen import det_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel(a, b):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, np.float64)
+    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def test_full_cfg2_batch_stage_by_stage_vs_cpp_leg():
+    from dd3d_amd.fused_step import FusedDistiller
+    from dd3d_amd.models.MEConv import MEConvExp
+    torch.manual_seed(0)
+    net = MEConvExp(in_channel=3, out_channel=10)
+    net.load_state_dict(det_state_dict(net, "net.MEConvExp"))
+    images, _, idx = mnist3d_like(10, 256, seed=0)
+    with FusedDistiller(images, idx, net.to(DEV).train(), ipc=10, device=DEV, seed=7, image_syn=init_synthetic(10, 10, 250, seed=0), graph=True) as f:
+        f.outer_step()
+        f.outer_step()                                   # capture + replay: the buffers below are the replayed graph's
+        assert f._graph is not None
+        torch.cuda.synchronize()
+        p, st = f.last["passes"][0], f._static
+        M0, M1, M2 = f.row_counts()[0]
+        N, B = int(st.n.item()), 10 * 10 + st.B
+        host = lambda t: t.detach().cpu().numpy()
+        # ---- maps of the merged batch (2660 clouds), bit for bit
+        coords, pt_off = host(st.coords[:N]).astype(np.float64), host(st.pt_off)
+        assert int(pt_off[-1]) == N and np.array_equal(coords[:, 0], np.repeat(np.arange(B), np.diff(pt_off)))
+        C0, inv, seg0 = CL.quantize_unique(coords[:, 1:], pt_off)
+        C1, par1, seg1 = CL.stride_coords(C0, B, 2)
+        C2, par2, seg2 = CL.stride_coords(C1, B, 4)
+        assert (C0.shape[0], C1.shape[0], C2.shape[0]) == (M0, M1, M2)
+        cm = p.cm
+        for s_, C, seg in ((1, C0, seg0), (2, C1, seg1), (4, C2, seg2)):
+            assert np.array_equal(host(cm.levels[s_].C[:C.shape[0]]), C) and np.array_equal(host(cm.seg_off(s_)), seg), s_
+        assert np.array_equal(host(cm.levels[1].inv[:N]), inv)
+        assert np.array_equal(host(cm.parent(2)[:M0]), par1) and np.array_equal(host(cm.parent(4)[:M1]), par2)
+        k0, _, p0, _, k1, _, p1 = p.maps[:7]
+        nbr0, nbr1, kid1, kid2 = CL.kernel_map(C0, 1), CL.kernel_map(C1, 2), CL.pool_map(C0, C1, 1), CL.pool_map(C1, C2, 2)
+        assert np.array_equal(host(k0[:, :M0]), nbr0) and np.array_equal(host(k1[:, :M1]), nbr1)
+        assert np.array_equal(host(p0[:, :M1]), kid1) and np.array_equal(host(p1[:, :M2]), kid2)
+        assert M1 >= 65536 and int((nbr1 >= 0).sum()) > 500_000
+        # ---- forward stages, each from the device's input of that stage (fp64 on the host)
+        W0, w1, b1, W1, w5, b5, Wc, bc = [host(t).astype(np.float64) for t in f.network.parameters()]
+        F0 = CL.voxel_mean_fwd(host(st.feats[:N]), inv, M0)
+        xh0, _ = CL.inorm_fwd(CL.conv_fwd(F0, W0, nbr0), seg0)
+        e_xh0 = rel(p.xh0[:M0], xh0)
+        P0, arg0 = CL.affine_relu_pool_fwd(host(p.xh0[:M0]), w1, b1, kid1)
+        e_P0 = rel(p.P0[:M1], P0)
+        same0 = float((host(p.arg0[:M1]) == arg0).mean())
+        xh1, _ = CL.inorm_fwd(CL.conv_fwd(host(p.P0[:M1]), W1, nbr1), seg1)
+        e_xh1 = rel(p.xh1[:M1], xh1)
+        P1, arg1 = CL.affine_relu_pool_fwd(host(p.xh1[:M1]), w5, b5, kid2)
+        e_P1 = rel(p.P1[:M2], P1)
+        same1 = float((host(p.arg1[:M2]) == arg1).mean())
+        print(f"rows {M0} / {M1} / {M2}; x-hat 0 {e_xh0:.1e}, pool 0 {e_P0:.1e} (arg-max equal {same0:.6f}), x-hat 1 {e_xh1:.1e}, pool 1 {e_P1:.1e} "
+              f"(arg-max equal {same1:.6f})")
+        assert e_xh0 < 2e-5 and e_xh1 < 2e-5 and e_P0 < 1e-6 and e_P1 < 1e-6
+        assert same0 > 0.9999 and same1 > 0.9999          # (a tie inside a window, or a pooled 0: either row is a maximum)
+        # ---- dense() + Linear per group (the minimum corner is the GROUP's batch, models/MEConv.py:251) and the cross entropy, class 3's real batch
+        G, c = f.G, 3
+        gco = host(st.gco)
+        b0, b1_ = int(gco[G + c]), int(gco[G + c + 1])
+        r0, r1 = int(seg2[b0]), int(seg2[b1_])
+        # (the device keeps the classifier over the OCCUPIED sites -- 7 x 7 for 28 x 28 digits at stride 4 -- the parameter has all 28 x 28)
+        assert tuple(f.site_extent()) == (1, 7, 7) and np.array_equal(host(p.dp.site[r0:r1]), CL.dense_sites(C2[r0:r1], 4, (1, 7, 7)))
+        site, S = CL.dense_sites(C2[r0:r1], 4, (1, 28, 28)), 784
+        segc = seg2[b0:b1_ + 1] - r0
+        logits = CL.sparse_linear_fwd(host(p.P1[r0:r1]), site, segc, S, Wc, bc)
+        assert rel(p.logits[b0:b1_], logits) < 1e-5
+        labels = np.full(b1_ - b0, f.classes[c], np.int32)
+        ce, dl = CL.softmax_ce(logits, labels)
+        # first-order gradients of the class's real batch: classifier weight and bias against the device's gradient list
+        gW = CL.sparse_linear_bwd_w(dl, host(p.P1[r0:r1]), site, segc, S)
+        gwr = f.last["gw_real"]
+        assert rel(gwr[7][c], dl.sum(0)) < 2e-5
+        assert rel(gwr[6][c].reshape(10, -1), gW) < 2e-5
