@@ -87,3 +87,55 @@ def test_full_cfg2_batch_stage_by_stage_vs_cpp_leg():
         gwr = f.last["gw_real"]
         assert rel(gwr[7][c], dl.sum(0)) < 2e-5
         assert rel(gwr[6][c].reshape(10, -1), gW) < 2e-5
+
+
+def test_cfg4_shaped_batch_maps_and_forward_vs_cpp_leg():
+    """The same dissection for volumetric clouds (BASELINE configs[3] shape: 1024-point shells in [-1,1]^3, voxel 0.05, all 27 offsets alive;
+    8 of the 40 classes x 256 real clouds + ipc 10 = 2 128 clouds, 2.2 M points): the LDS map builder k_cloud_emit<1024> against the C++ leg's
+    hash-table builder bit for bit -- the quotient point / voxel size is the device's (st.coords), the floor is the host's --, then the forward
+    stages from the device's own inputs."""
+    from dd3d_amd.fused_step import FusedDistiller
+    from dd3d_amd.models.MEConv import MEConvExp
+    from dd3d_amd.synthetic import shell_clouds
+    nclass, per, ipc, npts, ext = 8, 256, 10, 1024, (12, 12, 12)
+    clouds = shell_clouds(nclass * per, npts, seed=1)
+    idx = [list(range(c * per, (c + 1) * per)) for c in range(nclass)]
+    syn = (torch.rand((nclass * ipc, npts, 3), generator=torch.Generator().manual_seed(1)) * 1.8 - 0.9).float()
+    torch.manual_seed(0)
+    net = MEConvExp(3, nclass, num_classes=nclass, dense_extent=ext)
+    net.load_state_dict(det_state_dict(net, "net.cfg4s"))
+    with FusedDistiller(None, idx, net.to(DEV).train(), graph=True, ipc=ipc, num_classes=nclass, num_points=npts, batch_size=per, device=DEV, seed=5,
+                        image_syn=syn, real_clouds=clouds, quantization_size=0.05, clamp_range=(-0.95, 0.95), zero_first_axis=False, dist_lr=1e-6) as f:
+        f.outer_step()
+        f.outer_step()
+        assert f._graph is not None
+        torch.cuda.synchronize()
+        p, st = f.last["passes"][0], f._static
+        M0, M1, M2 = f.row_counts()[0]
+        N, B = int(st.n.item()), nclass * ipc + st.B
+        host = lambda t: t.detach().cpu().numpy()
+        coords, pt_off = host(st.coords[:N]).astype(np.float64), host(st.pt_off)
+        C0, inv, seg0 = CL.quantize_unique(coords[:, 1:], pt_off)
+        C1, par1, seg1 = CL.stride_coords(C0, B, 2)
+        C2, par2, seg2 = CL.stride_coords(C1, B, 4)
+        assert (C0.shape[0], C1.shape[0], C2.shape[0]) == (M0, M1, M2) and M0 > 900_000
+        cm = p.cm
+        for s_, C, seg in ((1, C0, seg0), (2, C1, seg1), (4, C2, seg2)):
+            assert np.array_equal(host(cm.levels[s_].C[:C.shape[0]]), C) and np.array_equal(host(cm.seg_off(s_)), seg), s_
+        assert np.array_equal(host(cm.levels[1].inv[:N]), inv)
+        assert np.array_equal(host(cm.parent(2)[:M0]), par1) and np.array_equal(host(cm.parent(4)[:M1]), par2)
+        k0, _, p0, _, k1, _, p1 = p.maps[:7]
+        nbr0, nbr1, kid1, kid2 = CL.kernel_map(C0, 1), CL.kernel_map(C1, 2), CL.pool_map(C0, C1, 1), CL.pool_map(C1, C2, 2)
+        assert np.array_equal(host(k0[:, :M0]), nbr0) and np.array_equal(host(k1[:, :M1]), nbr1)
+        assert np.array_equal(host(p0[:, :M1]), kid1) and np.array_equal(host(p1[:, :M2]), kid2)
+        assert all(int((nbr1[k] >= 0).sum()) > 0 for k in range(27))
+        W0, w1, b1, W1, w5, b5, Wc, bc = [host(t).astype(np.float64) for t in f.network.parameters()]
+        F0 = CL.voxel_mean_fwd(host(st.feats[:N]), inv, M0)
+        xh0, _ = CL.inorm_fwd(CL.conv_fwd(F0, W0, nbr0), seg0)
+        P0, arg0 = CL.affine_relu_pool_fwd(host(p.xh0[:M0]), w1, b1, kid1)
+        xh1, _ = CL.inorm_fwd(CL.conv_fwd(host(p.P0[:M1]), W1, nbr1), seg1)
+        P1, arg1 = CL.affine_relu_pool_fwd(host(p.xh1[:M1]), w5, b5, kid2)
+        e = [rel(p.xh0[:M0], xh0), rel(p.P0[:M1], P0), rel(p.xh1[:M1], xh1), rel(p.P1[:M2], P1)]
+        same = [float((host(p.arg0[:M1]) == arg0).mean()), float((host(p.arg1[:M2]) == arg1).mean())]
+        print(f"rows {M0} / {M1} / {M2}; x-hat 0 {e[0]:.1e}, pool 0 {e[1]:.1e}, x-hat 1 {e[2]:.1e}, pool 1 {e[3]:.1e}; arg-max equal {same[0]:.6f} / {same[1]:.6f}")
+        assert e[0] < 2e-5 and e[2] < 2e-5 and e[1] < 1e-6 and e[3] < 1e-6 and min(same) > 0.9999
