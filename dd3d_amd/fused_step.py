@@ -1318,6 +1318,11 @@ class FusedDistiller:
         # streams had the default priority never finished (measured on ROCm 7.2: the launching stream waits for its side streams' events
         # while its own queue outranks theirs)
         prio = getattr(torch.cuda.current_stream(self.device), "priority", 0)
+        if self.use_graph and 0 < int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 4:
+            # measured on ROCm 7.2: with two hardware queues per process the first launch of the captured three-branch graph ends in a HOST
+            # segmentation fault inside hipGraphLaunch (with eight the replay is three times slower); HIP's default is four
+            raise RuntimeError("graph mode needs GPU_MAX_HW_QUEUES >= 4 (HIP's default): with fewer hardware queues hipGraphLaunch faults on "
+                               "ROCm 7.2 for this step's three-branch graph; unset the variable or use graph=False")
         if prio != 0 and self.use_graph:
             # (eager steps run there once the side streams share the priority; the REPLAY of the captured graph did not return: the
             # runtime's own graph streams keep the default priority)

@@ -103,6 +103,23 @@ def test_fused_sampling_is_seeded_and_runs_at_bench_shape():
     assert np.isfinite(outs[0][0]).all()
 
 
+def test_graph_mode_refuses_fewer_hardware_queues_than_the_default(monkeypatch):
+    """GPU_MAX_HW_QUEUES below HIP's default of 4: hipGraphLaunch of the three-branch step graph faults on the host on ROCm 7.2 (measured with 2,
+    DESIGN.md section 4), so graph mode refuses up front; the eager path is not affected.  (The variable is read by the runtime when it
+    starts: setting it here changes what the guard sees, not the runtime.)"""
+    from dd3d_amd.fused_step import FusedDistiller
+    from dd3d_amd.synthetic import mnist3d_like
+    images, _, idx = mnist3d_like(3, 30, seed=3)
+    kw = dict(ipc=2, num_classes=3, batch_size=16, device=DEV, seed=11, image_syn=init_synthetic(3, 2, 250, seed=1))
+    with FusedDistiller(images, idx, _net(), graph=True, **kw) as f, FusedDistiller(images, idx, _net(), graph=False, **kw) as e:
+        monkeypatch.setenv("GPU_MAX_HW_QUEUES", "2")
+        with pytest.raises(RuntimeError, match="GPU_MAX_HW_QUEUES"):
+            f.outer_step()
+        assert np.isfinite(e.outer_step().item())
+        monkeypatch.setenv("GPU_MAX_HW_QUEUES", "4")
+        assert np.isfinite(f.outer_step().item())
+
+
 def test_workspace_of_a_finished_capture_cannot_grow():
     """_lib.workspace: a block may grow while the capture that first asked for it is still being recorded (stream-ordered reuse inside one
     recording), but once a capture has ended the graph holds the ADDRESS -- a larger request under the same (stream, scope) key, eager or
