@@ -139,3 +139,61 @@ def test_cfg4_shaped_batch_maps_and_forward_vs_cpp_leg():
         same = [float((host(p.arg0[:M1]) == arg0).mean()), float((host(p.arg1[:M2]) == arg1).mean())]
         print(f"rows {M0} / {M1} / {M2}; x-hat 0 {e[0]:.1e}, pool 0 {e[1]:.1e}, x-hat 1 {e[2]:.1e}, pool 1 {e[3]:.1e}; arg-max equal {same[0]:.6f} / {same[1]:.6f}")
         assert e[0] < 2e-5 and e[2] < 2e-5 and e[1] < 1e-6 and e[3] < 1e-6 and min(same) > 0.9999
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_ragged_configurations_vs_cpp_leg(seed):
+    """Ten random small configurations of the whole step -- 1 to 4 classes (also a subset of them owned), 1 to 9 real clouds per class of
+    RAGGED sizes (1 to ``npts`` points: one-point clouds, clouds that share voxels), ipc 1 to 3, 3-D clouds with voxel size 0.05 / 0.1 / 0.5 or
+    flat digit images, any of the four metrics, graph or eager -- two steps each against the C++/OpenMP oracle leg in fp64: per-class loss and
+    xyz gradient within 1e-4 (a class on a ReLU / arg-max flip would show here as a failure: none of the ten has one)."""
+    from dd3d_amd.fused_step import FusedDistiller
+    from dd3d_amd.models.MEConv import MEConvExp
+    from dd3d_amd.synthetic import shell_clouds, stroke_digits
+    rng = np.random.RandomState(100 + seed)
+    nclass, per, ipc = int(rng.randint(1, 5)), int(rng.randint(1, 10)), int(rng.randint(1, 4))
+    metric = ["modmse", "ours", "mse", "cos"][seed % 4]
+    flat = seed % 3 == 0
+    own = sorted(rng.choice(nclass, size=int(rng.randint(1, nclass + 1)), replace=False).tolist())
+    graph = bool(seed % 2)
+    torch.manual_seed(seed)
+    if flat:
+        npts, q, ext = 250, 1, (1, 28, 28)
+        images = torch.cat([stroke_digits(per, seed=300 + seed * 7 + c) for c in range(nclass)])
+        images[0] = 0
+        images[0, 0, 9, 11] = 1                                             # a one-point cloud
+        net = MEConvExp(in_channel=3, out_channel=10)
+        kw = dict(images_all=images, real_clouds=None)
+        syn = init_synthetic(nclass, ipc, npts, seed=seed)
+        clamp = lambda t: t.clamp(0, 27).mul(torch.tensor([0.0, 1.0, 1.0]))
+    else:
+        npts, q, ext = int(rng.choice([40, 150, 300])), float(rng.choice([0.05, 0.1, 0.5])), (12, 12, 12)
+        clouds = [c[:int(rng.randint(1, npts + 1))] for c in shell_clouds(nclass * per, npts, seed=seed)]
+        clouds[-1] = clouds[-1][:1]
+        net = MEConvExp(3, nclass, num_classes=nclass, dense_extent=ext)
+        kw = dict(images_all=None, real_clouds=clouds, quantization_size=q, clamp_range=(-0.95, 0.95), zero_first_axis=False, num_points=npts)
+        syn = (torch.rand((nclass * ipc, npts, 3), generator=torch.Generator().manual_seed(seed)) * 1.8 - 0.9).float()
+        clamp = lambda t: t.clamp(-0.95, 0.95)
+    net.load_state_dict(det_state_dict(net, "net.rand%d" % seed))
+    net64 = CL.Network(net, np.float64)
+    idx = [list(range(c * per, (c + 1) * per)) for c in range(nclass)]
+    images_all = kw.pop("images_all")
+    with FusedDistiller(images_all, idx, net.to(DEV).train(), ipc=ipc, num_classes=nclass if not flat else 10, batch_size=per, dist_opt=metric, device=DEV,
+                        seed=seed, image_syn=syn, classes=own, graph=graph, dist_lr=1e-3 if not flat else 0.1, **kw) as f:
+        draw = np.random.RandomState(seed)
+        for step in range(2):
+            pts = clamp(f.image_syn.detach().cpu()).double().numpy()
+            order = {c: draw.permutation(np.asarray(idx[c]))[:per] for c in own}
+            f.outer_step()
+            pc, grad = f.last["per_class"].cpu().double().numpy(), f.last["grad"].cpu().double().numpy()
+            for gi, c in enumerate(own):
+                reals = CL.image_clouds(images_all[order[c]].numpy()) if flat else [clouds[i].double().numpy() for i in order[c]]
+                l, g, _, _ = CL.class_step(net64, reals, [pts[c * ipc + i] for i in range(ipc)], c, metric, q)
+                mine = grad[c * ipc:(c + 1) * ipc].reshape(-1, 3)
+                if l == 0.0:   # one class = a one-output classifier: the cross entropy is constant, every gradient and the loss are exactly zero
+                    assert nclass == 1 and pc[gi] == 0.0 and not mine.any() and not g.any()
+                    continue
+                e_l = abs(pc[gi] - l) / abs(l)
+                e_g = float(np.linalg.norm(mine - g) / max(np.linalg.norm(g), 1e-300))
+                assert e_l < 1e-4 and e_g < 1e-4, (seed, step, c, metric, flat, e_l, e_g)
+        f.check()
